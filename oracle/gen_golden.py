@@ -1,0 +1,350 @@
+"""TEST INFRASTRUCTURE — generates tests/golden/*.npz by running the REFERENCE's own
+nn.Modules (imported read-only from /root/reference via oracle/ref_harness.py) on
+seeded synthetic checkpoints.  Run in the build container only:
+
+    python oracle/gen_golden.py
+
+The reference's ModelRunner cannot be instantiated on CPU (it hard-wires NCCL and
+CUDA, P/engine/model_runner/base.py:47-56), so this script drives the modules
+directly and reproduces the runners' batch metadata (positions, slot mapping,
+context lengths, block tables) exactly as prepare_prefill / prepare_decode(_talker)
+build them.  Fixtures hold inputs, expected outputs and the seeds of the synthetic
+weights — never reference source.
+"""
+import importlib
+import importlib.util
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+os.environ["TORCHDYNAMO_DISABLE"] = "1"
+
+import numpy as np
+import torch
+
+import ref_harness
+
+OUT = os.path.join(ROOT, "tests", "golden")
+BLOCK = 256
+
+
+def _load_synthetic():
+    spec = importlib.util.spec_from_file_location(
+        "qtts_synthetic", os.path.join(ROOT, "nano-qwen3tts-vllm_amd", "utils", "synthetic.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def f32(t):
+    return t.detach().float().cpu().numpy()
+
+
+def build_models(ref, syn, size, seed):
+    cfgmod = importlib.import_module("nano_qwen3tts_vllm.config")
+    talker_mod = importlib.import_module("nano_qwen3tts_vllm.models.qwen3_tts_talker")
+    pred_mod = importlib.import_module("nano_qwen3tts_vllm.models.qwen3_tts_predictor")
+    cfg = syn.make_config(size)
+    sd = syn.make_state_dict(cfg, seed=seed, norm_jitter=0.1, with_text=True, embed_std=0.05)
+    full = cfgmod.Qwen3TTSConfig(**json.loads(json.dumps(cfg)))
+    torch.set_default_dtype(torch.bfloat16)      # as the runner does (base.py:55)
+    talker = talker_mod.Qwen3TTSTalkerForCausalLM(full.talker_config)
+    talker.load_state_dict(sd)
+    pc = full.talker_config.code_predictor_config
+    pc.talker_hidden_size = full.talker_config.hidden_size
+    pred = pred_mod.Qwen3TTSCodePredictorForCausalLM(pc, full.talker_config)
+    pred.load_state_dict(sd)
+    torch.set_default_dtype(torch.float32)
+    return cfg, sd, talker.eval(), pred.eval()
+
+
+def attach_kv(model, n_layers, n_blocks, kvh, hd):
+    kv = torch.zeros(2, n_layers, n_blocks, BLOCK, kvh, hd, dtype=torch.bfloat16)
+    lid = 0
+    for m in model.modules():
+        if hasattr(m, "k_cache") and hasattr(m, "v_cache"):
+            m.k_cache = kv[0, lid]
+            m.v_cache = kv[1, lid]
+            lid += 1
+    assert lid == n_layers
+    return kv
+
+
+def slots_for(block_table, start, end):
+    return [block_table[t // BLOCK] * BLOCK + t % BLOCK for t in range(start, end)]
+
+
+@torch.inference_mode()
+def gen_ops(ref):
+    ln = importlib.import_module("nano_qwen3tts_vllm.layers.layernorm")
+    rope = importlib.import_module("nano_qwen3tts_vllm.layers.rotary_embedding")
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    x = (torch.randn(5, 256, generator=g) * 2).bfloat16()
+    w = (1 + 0.1 * torch.randn(256, generator=g)).bfloat16()
+    n = ln.Qwen3TTSRMSNorm(256, eps=1e-6)
+    n.weight.data = w
+    out.update(rms_x=f32(x), rms_w=f32(w), rms_y=f32(n(x)))
+    xh = (torch.randn(5, 4, 128, generator=g) * 3).bfloat16()
+    wh = (1 + 0.1 * torch.randn(128, generator=g)).bfloat16()
+    n2 = ln.Qwen3TTSRMSNorm(128, eps=1e-6)
+    n2.weight.data = wh
+    out.update(hn_x=f32(xh), hn_w=f32(wh), hn_y=f32(n2(xh)))
+    pos = torch.tensor([0, 1, 2, 7, 300, 1023], dtype=torch.int64)
+    q = torch.randn(6, 4, 128, generator=g).bfloat16()
+    k = torch.randn(6, 2, 128, generator=g).bfloat16()
+    r3 = rope.get_rope(128, 128, 32768, 1000000.0,
+                       {"mrope_section": [24, 20, 20], "interleaved": True})
+    qo, ko = r3(pos, q, k)
+    out.update(rope_pos=pos.numpy(), rope_q=f32(q), rope_k=f32(k), mrope_qo=f32(qo), mrope_ko=f32(ko))
+    r1 = rope.get_rope(128, 128, 32768, 1000000.0, None)
+    qo, ko = r1(pos, q, k)
+    out.update(rope1d_qo=f32(qo), rope1d_ko=f32(ko))
+    r3n = rope.get_rope(128, 128, 32768, 10000.0, {"mrope_section": [24, 20, 20], "interleaved": False})
+    qo, ko = r3n(pos, q, k)
+    out.update(mrope_ni_qo=f32(qo), mrope_ni_ko=f32(ko))
+    act = importlib.import_module("nano_qwen3tts_vllm.layers.activation")
+    ga = (torch.randn(4, 512, generator=g) * 3).bfloat16()
+    up = torch.randn(4, 512, generator=g).bfloat16()
+    out.update(act_g=f32(ga), act_u=f32(up), act_y=f32(act.Silu()(ga) * up))
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **out)
+    print("ops.npz", len(out))
+
+
+@torch.inference_mode()
+def gen_models(ref, syn, size, seed, tag):
+    ctx = importlib.import_module("nano_qwen3tts_vllm.utils.context")
+    cfg, sd, talker, pred = build_models(ref, syn, size, seed)
+    t = cfg["talker_config"]
+    p = t["code_predictor_config"]
+    H = t["hidden_size"]
+    out = {"seed": np.int64(seed),
+           "weight_checksum": np.float64(sum(float(v.float().abs().sum()) for v in sd.values()))}
+    g = torch.Generator().manual_seed(seed + 1)
+
+    # ---------------- talker: prefill of 3 packed prompts, then 3 decode steps
+    n_blocks = 8
+    kv = attach_kv(talker, t["num_hidden_layers"], n_blocks, t["num_key_value_heads"], t["head_dim"])
+    lens = [5, 9, 260]
+    tables = [[3], [0], [5, 1]]
+    prompts = [(torch.randn(L, H, generator=g) * 0.5) for L in lens]       # fp32 inputs
+    x = torch.cat(prompts, 0).to(torch.bfloat16)
+    pos, slots, cu = [], [], [0]
+    for L, bt in zip(lens, tables):
+        pos += list(range(L))
+        slots += slots_for(bt, 0, L)
+        cu.append(cu[-1] + L)
+    cu_t = torch.tensor(cu, dtype=torch.int32)
+    ctx.set_context(True, cu_t, cu_t, max(lens), max(lens), torch.tensor(slots, dtype=torch.int32), None, None)
+    hs = talker(x, torch.tensor(pos, dtype=torch.int64))
+    logits = talker.compute_logits(hs)            # gathers last rows itself (embed_head.py:58-60)
+    last = cu_t[1:].long() - 1
+    hl = hs[last].contiguous()
+    ctx.reset_context()
+    for i, pr in enumerate(prompts):
+        out[f"t_prompt{i}"] = pr.numpy()
+    out.update(t_lens=np.array(lens), t_tables=np.array([bt + [-1] * (2 - len(bt)) for bt in tables]),
+               t_prefill_hidden=f32(hl), t_prefill_logits=f32(logits), t_prefill_all_hidden=f32(hs))
+    num_tokens = [L + 1 for L in lens]            # append_token after prefill
+    for step in range(3):
+        emb = (torch.randn(3, H, generator=g) * 0.5)
+        positions = torch.tensor(num_tokens, dtype=torch.int64)              # Q1: position = len(seq)
+        sl = torch.tensor([slots_for(bt, n - 1, n)[0] for bt, n in zip(tables, num_tokens)], dtype=torch.int32)
+        cl = torch.tensor(num_tokens, dtype=torch.int32)
+        bt_t = torch.tensor([bt + [-1] * (2 - len(bt)) for bt in tables], dtype=torch.int32)
+        ctx.set_context(False, slot_mapping=sl, context_lens=cl, block_tables=bt_t)
+        hs = talker(emb.to(torch.bfloat16), positions)
+        lg = talker.compute_logits(hs)
+        ctx.reset_context()
+        out[f"t_dec{step}_in"] = emb.numpy()
+        out[f"t_dec{step}_hidden"] = f32(hs)
+        out[f"t_dec{step}_logits"] = f32(lg)
+        num_tokens = [n + 1 for n in num_tokens]
+
+    # ---------------- predictor: burst of B=3 (prefill 2 tokens, 14 decodes), greedy
+    B = 3
+    pkv = attach_kv(pred, p["num_hidden_layers"], 4, p["num_key_value_heads"], p["head_dim"])
+    ptabs = [[2], [0], [3]]
+    pin = torch.randn(B, 2, H, generator=g) * 0.5
+    out["p_in"] = pin.numpy()
+    embeds = pred.get_input_embeddings(None, pin.view(1, 2 * B, H).to(torch.bfloat16), [0] * B)
+    cu_p = torch.tensor([0, 2, 4, 6], dtype=torch.int32)
+    sl = torch.tensor(sum([slots_for(bt, 0, 2) for bt in ptabs], []), dtype=torch.int32)
+    ctx.set_context(True, cu_p, cu_p, 2, 2, sl, None, None)
+    hs = pred(embeds.view(-1, H), torch.tensor([0, 1] * B, dtype=torch.int64))
+    lg = pred.compute_logits(hs, [0] * B)
+    ctx.reset_context()
+    all_logits = [f32(lg)]
+    tok = torch.argmax(lg.float(), dim=-1)
+    toks = [tok.clone()]
+    n_tok = 3
+    for step in range(1, 15):
+        embeds = pred.get_input_embeddings(tok, None, [step] * B)            # table step-1
+        positions = torch.tensor([n_tok - 1] * B, dtype=torch.int64)
+        sl = torch.tensor([bt[0] * BLOCK + n_tok - 1 for bt in ptabs], dtype=torch.int32)
+        cl = torch.tensor([n_tok] * B, dtype=torch.int32)
+        ctx.set_context(False, slot_mapping=sl, context_lens=cl,
+                        block_tables=torch.tensor(ptabs, dtype=torch.int32))
+        hs = pred(embeds, positions)
+        lg = pred.compute_logits(hs, [step] * B)
+        ctx.reset_context()
+        all_logits.append(f32(lg))
+        tok = torch.argmax(lg.float(), dim=-1)
+        toks.append(tok.clone())
+        n_tok += 1
+    out["p_tokens"] = torch.stack(toks, 1).numpy()
+    out["p_logits"] = np.stack(all_logits, 1)
+
+    # ---------------- frame loop: 2 streams x 6 frames through both modules + the API glue
+    S, NF = 2, 6
+    kv.zero_()
+    pkv.zero_()
+    lens = [7, 12]
+    tables = [[2], [4]]
+    prompts = [(torch.randn(L, H, generator=g) * 0.5) for L in lens]
+    text_adds = torch.randn(S, NF, H, generator=g) * 0.3
+    emb_t = talker.get_input_embeddings().weight.float()                     # fp32 copies (embedding_loader.py:40-50)
+    emb_p = [m.weight.float() for m in pred.model.codec_embedding]
+    pos, slots, cu = [], [], [0]
+    for L, bt in zip(lens, tables):
+        pos += list(range(L))
+        slots += slots_for(bt, 0, L)
+        cu.append(cu[-1] + L)
+    cu_t = torch.tensor(cu, dtype=torch.int32)
+    ctx.set_context(True, cu_t, cu_t, max(lens), max(lens), torch.tensor(slots, dtype=torch.int32), None, None)
+    hs = talker(torch.cat(prompts, 0).to(torch.bfloat16), torch.tensor(pos, dtype=torch.int64))
+    lg = talker.compute_logits(hs)
+    hl = hs[cu_t[1:].long() - 1].contiguous()
+    ctx.reset_context()
+    num_tokens = [L + 1 for L in lens]
+    frames = np.zeros((S, NF, 16), dtype=np.int64)
+    margins = np.zeros((S, NF), dtype=np.float32)
+    for f in range(NF):
+        top2 = torch.topk(lg.float(), 2, dim=-1)[0]
+        margins[:, f] = (top2[:, 0] - top2[:, 1]).numpy()
+        tok0 = torch.argmax(lg.float(), dim=-1)
+        # predictor input: cat(hidden, emb(token)) in fp32 on the wire (interface.py:1242-1252)
+        pin = torch.stack([torch.stack([hl[i].float(), emb_t[tok0[i]]], 0) for i in range(S)], 0)
+        embeds = pred.get_input_embeddings(None, pin.view(1, 2 * S, H).to(torch.bfloat16), [0] * S)
+        cu_p = torch.tensor([0, 2, 4], dtype=torch.int32)
+        ptabs = [[1], [0]]
+        sl = torch.tensor(sum([slots_for(bt, 0, 2) for bt in ptabs], []), dtype=torch.int32)
+        ctx.set_context(True, cu_p, cu_p, 2, 2, sl, None, None)
+        ph = pred(embeds.view(-1, H), torch.tensor([0, 1] * S, dtype=torch.int64))
+        plg = pred.compute_logits(ph, [0] * S)
+        ctx.reset_context()
+        tok = torch.argmax(plg.float(), dim=-1)
+        ptoks = [tok.clone()]
+        n_tok = 3
+        for step in range(1, 15):
+            embeds = pred.get_input_embeddings(tok, None, [step] * S)
+            ctx.set_context(False, slot_mapping=torch.tensor([bt[0] * BLOCK + n_tok - 1 for bt in ptabs], dtype=torch.int32),
+                            context_lens=torch.tensor([n_tok] * S, dtype=torch.int32),
+                            block_tables=torch.tensor(ptabs, dtype=torch.int32))
+            ph = pred(embeds, torch.tensor([n_tok - 1] * S, dtype=torch.int64))
+            plg = pred.compute_logits(ph, [step] * S)
+            ctx.reset_context()
+            tok = torch.argmax(plg.float(), dim=-1)
+            ptoks.append(tok.clone())
+            n_tok += 1
+        ptoks = torch.stack(ptoks, 1)
+        nxt = []
+        for i in range(S):
+            frames[i, f, 0] = int(tok0[i])
+            frames[i, f, 1:] = ptoks[i].numpy()
+            last_id_hidden = emb_t[tok0[i]].view(1, 1, H)
+            codec_hiddens = torch.cat([last_id_hidden] + [emb_p[j][ptoks[i, j]].view(1, 1, H) for j in range(15)], dim=1)
+            e = codec_hiddens.sum(1, keepdim=True) + text_adds[i, f].view(1, 1, H)   # interface.py:1276-1285
+            nxt.append(e[0, 0])
+        if f + 1 < NF:
+            emb = torch.stack(nxt, 0)
+            ctx.set_context(False,
+                            slot_mapping=torch.tensor([slots_for(bt, n - 1, n)[0] for bt, n in zip(tables, num_tokens)], dtype=torch.int32),
+                            context_lens=torch.tensor(num_tokens, dtype=torch.int32),
+                            block_tables=torch.tensor(tables, dtype=torch.int32))
+            hl = talker(emb.to(torch.bfloat16), torch.tensor(num_tokens, dtype=torch.int64))
+            lg = talker.compute_logits(hl)
+            ctx.reset_context()
+            num_tokens = [n + 1 for n in num_tokens]
+    for i, pr in enumerate(prompts):
+        out[f"f_prompt{i}"] = pr.numpy()
+    out.update(f_text_adds=text_adds.numpy(), f_frames=frames, f_margins=margins)
+    np.savez_compressed(os.path.join(OUT, f"model_{tag}.npz"), **out)
+    print(f"model_{tag}.npz", frames[0, :, :4].tolist(), "min margin", margins.min())
+
+
+def gen_sched(ref):
+    """Scheduling traces from the reference's pure-Python Scheduler / BlockManager /
+    TalkerScheduler (P/engine/scheduler.py, block_manager.py, llm_engine/talker_llm_engine.py)."""
+    from types import SimpleNamespace
+    seqmod = importlib.import_module("nano_qwen3tts_vllm.engine.sequence")
+    schedmod = importlib.import_module("nano_qwen3tts_vllm.engine.scheduler")
+    tmod = importlib.import_module("nano_qwen3tts_vllm.engine.llm_engine.talker_llm_engine")
+    spmod = importlib.import_module("nano_qwen3tts_vllm.sampling_params")
+    cfg = SimpleNamespace(max_num_seqs=4, max_num_batched_tokens=2048, eos=-1, num_kvcache_blocks=6,
+                          kvcache_block_size=256)
+    trace = {"talker": [], "predictor": []}
+    # talker: 3 requests (one spanning 2 blocks), decode inputs fed for a subset each round
+    ts = tmod.TalkerScheduler(cfg)
+    sp = spmod.SamplingParams(temperature=1.0, max_tokens=1)
+    lens = {"a": 10, "b": 255, "c": 300}
+    seqs = {}
+    for rid, L in lens.items():
+        s = seqmod.Sequence([], input_embeds=torch.zeros(1, L, 8), sampling_params=sp, request_id=rid)
+        ts.request_id_to_seq[rid] = s
+        ts.add(s)
+        seqs[rid] = s
+
+    def snap(batch, is_prefill):
+        return {"prefill": bool(is_prefill),
+                "seqs": [{"rid": s.request_id, "len": len(s), "block_table": list(s.block_table),
+                          "last_block_num_tokens": s.last_block_num_tokens} for s in batch],
+                "free": list(ts.block_manager.free_block_ids)}
+
+    batch, pre = ts.schedule()
+    trace["talker"].append(snap(batch, pre))
+    ts.postprocess(batch, [11] * len(batch), [None] * len(batch))
+    feeds = [["a", "b", "c"], ["b"], ["a", "b", "c"], ["c", "a"]]
+    for fd in feeds:
+        for rid in fd:
+            seqs[rid].decode_input_embeds = torch.zeros(1, 1, 8)
+        batch, pre = ts.schedule()
+        trace["talker"].append({"fed": fd, **snap(batch, pre)})
+        ts.postprocess(batch, [12] * len(batch), [None] * len(batch))
+    ts.clear_request("b")
+    trace["talker"].append({"cleared": "b", "free": list(ts.block_manager.free_block_ids),
+                            "running": [s.request_id for s in ts.running]})
+    # predictor: base scheduler, 3 bursts to completion
+    ps = schedmod.Scheduler(cfg)
+    sp = spmod.SamplingParams(temperature=0.9, max_tokens=17)
+    for rid in ["x", "y", "z"]:
+        ps.add(seqmod.Sequence([], input_embeds=torch.zeros(1, 2, 8), sampling_params=sp, request_id=rid))
+    steps = 0
+    while not ps.is_finished():
+        batch, pre = ps.schedule()
+        rec = {"prefill": bool(pre), "seqs": [{"rid": s.request_id, "len": len(s), "block_table": list(s.block_table)} for s in batch]}
+        ps.postprocess(batch, [5] * len(batch))
+        rec["finished"] = [s.request_id for s in batch if s.is_finished]
+        rec["free"] = list(ps.block_manager.free_block_ids)
+        trace["predictor"].append(rec)
+        steps += 1
+    with open(os.path.join(OUT, "sched.json"), "w") as f:
+        json.dump(trace, f, indent=1)
+    print("sched.json", len(trace["talker"]), steps)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_harness.load_reference()
+    syn = _load_synthetic()
+    gen_ops(ref)
+    gen_models(ref, syn, "tiny", 11, "tiny")
+    gen_models(ref, syn, "tiny-id", 12, "tiny_id")
+    gen_sched(ref)
+
+
+if __name__ == "__main__":
+    main()
