@@ -1,0 +1,180 @@
+/*
+ * qtts_hip.h — C ABI of libqtts_hip.so: the MI355X (gfx950) kernels behind the
+ * Qwen3-TTS talker + code-predictor `run_step` hot path.
+ *
+ * The reference (tsdocode/nano-qwen3tts-vllm) is pure Python and has no FFI of its
+ * own; each entry point below cites the reference function it replaces
+ * (P = nano-qwen3tts-vllm/ in the reference tree).  All pointers are DEVICE
+ * pointers unless stated otherwise, all tensors are dense row-major, `bf16` is
+ * the 16-bit brain float stored as uint16_t.  Every function is asynchronous on
+ * `stream` (a hipStream_t passed as void*), allocates nothing, never
+ * synchronises, and is therefore legal under hipStreamBeginCapture.
+ *
+ * Return value: 0 on success, a negative QTTS_E* code on a rejected argument
+ * (nothing was launched), or a positive hipError_t from the launch.
+ * qtts_last_error() returns a thread-local message for the last failure.
+ */
+#ifndef QTTS_HIP_H
+#define QTTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QTTS_OK 0
+#define QTTS_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define QTTS_ESTATE (-2)   /* model handle not fully configured */
+
+#define QTTS_KV_BLOCK 256  /* tokens per KV block (P/engine/sequence.py:16, P/config.py:52,60) */
+#define QTTS_HEAD_DIM 128  /* the only head size the released checkpoints use */
+
+typedef void *qtts_stream_t;
+
+int qtts_version(void);
+const char *qtts_last_error(void);
+
+/* ---------------------------------------------------------------- weights
+ * F.linear weights [N,K] (P/layers/linear.py:25) are re-laid once at load time
+ * into MFMA fragment order so that one wave-instruction reads 1 KiB contiguous:
+ *   packed[nt][ks][lane][j] = W[16*nt + (lane&15)][32*ks + 8*(lane>>4) + j]
+ * nt < N/16, ks < K/32, lane < 64, j < 8.  Requires N % 16 == 0, K % 32 == 0.
+ * `gate_up` interleaves two [I,K] matrices tile-wise (tile 2t = gate rows
+ * 16t.., tile 2t+1 = up rows 16t..) for the fused SwiGLU epilogue. */
+size_t qtts_packed_weight_bytes(int N, int K);
+int qtts_pack_weight(const void *w_rowmajor, void *packed, int N, int K, qtts_stream_t stream);
+int qtts_pack_gate_up(const void *gate, const void *up, void *packed, int I, int K, qtts_stream_t stream);
+
+/* ---------------------------------------------------------------- operators */
+
+/* out[M,N] = x[M,K] @ W^T (+bias[N]) (+residual[M,N]); fp32 accumulate, one
+ * rounding to bf16 after the bias, a second after the residual add — the
+ * rounding points of F.linear followed by `residual + y`
+ * (P/layers/linear.py:72-73,147-153; P/models/qwen3_tts_share.py:171,175).
+ * If norm_w != NULL the rows of x are RMS-normalised first exactly as
+ * P/layers/layernorm.py:17-27 (fp32 statistics, bf16, then * norm_w).
+ * ldx/ldo/ldr are row strides in elements. */
+int qtts_linear(const void *x, int ldx, const void *w_packed, const void *bias,
+                const void *residual, int ldr, const void *norm_w, float eps,
+                void *out, int ldo, int M, int N, int K, qtts_stream_t stream);
+
+/* out[M,I] = silu(x@Wg^T) * (x@Wu^T) with the reference's two roundings
+ * (P/models/qwen3_tts_share.py:131-135, P/layers/activation.py:11-13);
+ * optional fused RMSNorm of x as above. */
+int qtts_linear_swiglu(const void *x, int ldx, const void *w_gate_up_packed,
+                       const void *norm_w, float eps, void *out, int ldo,
+                       int M, int I, int K, qtts_stream_t stream);
+
+/* y = rmsnorm(x) * w  (P/layers/layernorm.py:17-27).  x,y [M,H]. */
+int qtts_rmsnorm(const void *x, int ldx, const void *w, float eps, void *y, int ldy,
+                 int M, int H, qtts_stream_t stream);
+
+/* Per-head RMSNorm of q and k, rotary embedding and KV-cache store in one pass
+ * (P/models/qwen3_tts_share.py:96-103, P/layers/rotary_embedding.py:33-34,
+ * P/layers/attention.py:10-30).  qkv is [N, (Hq+2*Hkv)*128] (q heads, then k
+ * heads, then v heads); q and k are rewritten in place.  rope_cos/rope_sin are
+ * bf16 tables [max_pos, 64] (the two halves of the reference's cos/sin rows are
+ * equal).  slot_mapping[i] == -1 skips the store; k_cache/v_cache may be NULL. */
+int qtts_qknorm_rope_store(void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w,
+                           float eps, const void *rope_cos, const void *rope_sin, int max_pos,
+                           const int64_t *positions, const int32_t *slot_mapping,
+                           void *k_cache, void *v_cache, int N, int Hq, int Hkv,
+                           qtts_stream_t stream);
+
+/* KV-cache scatter alone (P/layers/attention.py:33-54): k,v [N,Hkv*128] rows with
+ * row strides ldk/ldv; caches [num_blocks,256,Hkv,128]; slot -1 skipped. */
+int qtts_store_kvcache(const void *k, int ldk, const void *v, int ldv, void *k_cache, void *v_cache,
+                       const int32_t *slot_mapping, int N, int Hkv, qtts_stream_t stream);
+
+/* Paged attention: row i of q attends to the first context_lens[i] cached tokens
+ * of sequence row_seq[i] (row_seq == NULL: sequence i) through
+ * block_tables[seq][max_blocks].  Serves both call sites of
+ * P/layers/attention.py:88-95: decode (one row per sequence, context_lens =
+ * cache_seqlens) and causal prefill (context_lens[i] = position+1 after the
+ * rows' K/V were stored).  context_lens[i] == 0 writes zeros.  fp32 softmax.
+ * workspace: qtts_attn_workspace_bytes(N, Hq, max_context) bytes of device scratch. */
+size_t qtts_attn_workspace_bytes(int N, int Hq, int max_context);
+int qtts_paged_attention(const void *q, int ldq, const void *k_cache, const void *v_cache,
+                         const int32_t *block_tables, int max_blocks, const int32_t *row_seq,
+                         const int32_t *context_lens, int max_context, float scale,
+                         void *out, int ldo, int N, int Hq, int Hkv, void *workspace,
+                         qtts_stream_t stream);
+
+/* Greedy pick: out[i] = argmax_j float(logits[i,j]), lowest j on ties (the build's
+ * do_sample=False path; P/sampling_params.py:9 carries the flag). */
+int qtts_argmax(const void *logits, int ld, int64_t *out, int M, int V, qtts_stream_t stream);
+
+/* Stochastic pick of P/layers/sampler.py:15-24: logits/temperature, keep values >=
+ * the top_k-th largest, softmax, one multinomial draw (counter-based RNG keyed
+ * by seed, offset and row — not torch's generator stream). V <= 4096. */
+int qtts_sample_topk(const void *logits, int ld, const float *temperatures, int top_k,
+                     uint64_t seed, uint64_t offset, int64_t *out, int M, int V,
+                     qtts_stream_t stream);
+
+/* Both picks behind one launch, for graphs that serve mixed batches: row i is greedy
+ * when greedy_flags != NULL && greedy_flags[i] != 0, otherwise drawn as
+ * qtts_sample_topk does.  offset_dev (nullable, device) is added to `offset` so a
+ * captured graph can advance its RNG counter between replays.  out[i*ldout]. */
+int qtts_pick_token(const void *logits, int ld, const float *temperatures,
+                    const uint8_t *greedy_flags, int top_k, uint64_t seed, uint64_t offset,
+                    const uint64_t *offset_dev, int64_t *out, int ldout, int M, int V,
+                    qtts_stream_t stream);
+
+/* out[i,:] = table[ids[i],:] (P/models/qwen3_tts_predictor.py:94-95). */
+int qtts_embedding_gather(const void *table, const int64_t *ids, void *out, int ldo,
+                          int M, int H, int vocab, qtts_stream_t stream);
+
+/* Per-frame glue kept on the device (P/interface.py:1242-1252,1276-1285):
+ * pred_in[b] = [hidden[b]; talker_emb[token0[b]]]                     ([B,2,H])
+ * next[b]    = bf16( sum_{c<16} emb_c[codes[b,c]] (fp32) + text_add[b] (fp32) ) */
+int qtts_predictor_input(const void *hidden, const void *talker_emb, const int64_t *token0,
+                         void *pred_in, int B, int H, int vocab, qtts_stream_t stream);
+int qtts_frame_glue(const void *talker_emb, const void *const *pred_emb_tables /* device array of 15 */,
+                    const int64_t *codes /* [B,16] */, const float *text_add /* [B,H] */,
+                    void *next /* [B,H] bf16 */, int B, int H, int talker_vocab, int pred_vocab,
+                    qtts_stream_t stream);
+
+/* ---------------------------------------------------------------- decoder stack
+ * One handle per model (talker or code predictor): the layer loop of
+ * P/models/qwen3_tts_talker.py:53-62 / qwen3_tts_predictor.py:30-44 with the
+ * layer body of P/models/qwen3_tts_share.py:79-113,163-176 as five launches. */
+typedef struct qtts_model qtts_model_t;
+
+qtts_model_t *qtts_model_create(int hidden, int n_layers, int n_heads, int n_kv_heads,
+                                int head_dim, int intermediate, float rms_eps);
+void qtts_model_destroy(qtts_model_t *m);
+int qtts_model_set_layer(qtts_model_t *m, int layer, const void *input_norm_w,
+                         const void *wqkv_packed, const void *q_norm_w, const void *k_norm_w,
+                         const void *wo_packed, const void *post_norm_w,
+                         const void *w_gate_up_packed, const void *w_down_packed);
+int qtts_model_set_final_norm(qtts_model_t *m, const void *w);
+int qtts_model_set_rope(qtts_model_t *m, const void *cos, const void *sin, int max_pos);
+/* kv: [2, n_layers, num_blocks, 256, n_kv_heads, 128] bf16 (P/engine/model_runner/base.py:158-164). */
+int qtts_model_set_kv_cache(qtts_model_t *m, void *kv, int num_blocks);
+size_t qtts_model_workspace_bytes(const qtts_model_t *m, int max_rows, int max_context);
+int qtts_model_set_workspace(qtts_model_t *m, void *ws, size_t bytes, int max_rows, int max_context);
+
+/* hidden_out[N,hidden] = final_norm(layers(x)).  Rows are tokens; see
+ * qtts_paged_attention for row_seq/context_lens (decode: row_seq NULL,
+ * context_lens as prepare_decode builds them; prefill: per-token).
+ * P/engine/model_runner/talker_mode_runner.py:51-114, predictor_model_runner.py:66-131. */
+int qtts_model_forward(qtts_model_t *m, const void *x, const int64_t *positions,
+                       const int32_t *slot_mapping, const int32_t *row_seq,
+                       const int32_t *context_lens, const int32_t *block_tables, int max_blocks,
+                       int max_context, int N, void *hidden_out, qtts_stream_t stream);
+
+/* ---------------------------------------------------------------- hipGraph helpers
+ * Capture a sequence of the calls above once per batch size and replay it
+ * (the role of torch.cuda.CUDAGraph in talker_mode_runner.py:157-192). */
+typedef struct qtts_graph qtts_graph_t;
+int qtts_graph_begin(qtts_stream_t stream);
+qtts_graph_t *qtts_graph_end(qtts_stream_t stream);
+int qtts_graph_launch(qtts_graph_t *g, qtts_stream_t stream);
+void qtts_graph_destroy(qtts_graph_t *g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QTTS_HIP_H */

@@ -1,0 +1,1068 @@
+// libqtts_hip — MI355X (gfx950 / CDNA4) kernels for the Qwen3-TTS talker and
+// code-predictor decode path.  C ABI in include/qtts_hip.h.
+//
+// Design notes
+//  * Decode is weight streaming: every linear layer reads its weight once per
+//    step.  Weights are re-laid at load time into MFMA fragment order so that a
+//    wave-instruction reads 1 KiB contiguous and feeds
+//    v_mfma_f32_16x16x32_bf16 directly (A = 16 weight rows, B = up to 16 token
+//    rows, fp32 accumulate).  K is split over the waves of a workgroup and
+//    reduced through LDS in a fixed order, so results are bitwise reproducible.
+//  * RMSNorm is folded into the consuming GEMM's prologue, SwiGLU and the
+//    residual add into the producing GEMM's epilogue, with the reference's
+//    bf16 rounding points kept (see qtts_hip.h).
+//  * Attention over the paged KV cache is HBM/L2 bound with two query heads
+//    per KV head: K/V rows go straight to VGPRs (16 lanes x 16 B per token),
+//    fp32 online softmax per 16-lane group, 128-token splits merged by a
+//    combine pass.
+//  * Nothing here allocates or synchronises; everything is graph-capturable.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+
+#include "qtts_hip.h"
+
+typedef uint16_t bf16_t;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+static thread_local char g_err[512] = "";
+#define QFAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
+#define QCHECK(cond, ...) do { if (!(cond)) QFAIL(QTTS_EINVAL, __VA_ARGS__); } while (0)
+#define QLAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    snprintf(g_err, sizeof(g_err), "%s: %s", __func__, hipGetErrorString(e_)); return (int)e_; } } while (0)
+
+extern "C" int qtts_version(void) { return 100; }
+extern "C" const char *qtts_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }   // round through bf16
+
+union Frag {
+    uint4 u;
+    u32x4_t n;
+    bf16x8_t v;
+    bf16_t h[8];
+};
+
+// ------------------------------------------------------------------ weight packing
+__global__ void pack_weight_kernel(const bf16_t *__restrict__ w, uint4 *__restrict__ packed,
+                                   int N, int K, int tile_stride, int tile_offset) {
+    // one thread per (nt, ks, lane)
+    const int KS = K >> 5;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)(N >> 4) * KS * 64;
+    if (idx >= total) return;
+    int lane = idx & 63;
+    long f = idx >> 6;
+    int ks = f % KS;
+    int nt = f / KS;
+    int r = lane & 15, g = lane >> 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(w + (size_t)(16 * nt + r) * K + 32 * ks + 8 * g);
+    size_t dst_tile = (size_t)nt * tile_stride + tile_offset;
+    packed[(dst_tile * KS + ks) * 64 + lane] = *src;
+}
+
+extern "C" size_t qtts_packed_weight_bytes(int N, int K) { return (size_t)N * K * 2; }
+
+extern "C" int qtts_pack_weight(const void *w, void *packed, int N, int K, qtts_stream_t stream) {
+    QCHECK(w && packed, "pack_weight: null pointer");
+    QCHECK(N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "pack_weight: need N%%16==0, K%%32==0 (N=%d K=%d)", N, K);
+    long total = (long)(N / 16) * (K / 32) * 64;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t *)w, (uint4 *)packed, N, K, 1, 0);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+extern "C" int qtts_pack_gate_up(const void *gate, const void *up, void *packed, int I, int K, qtts_stream_t stream) {
+    QCHECK(gate && up && packed, "pack_gate_up: null pointer");
+    QCHECK(I > 0 && K > 0 && I % 16 == 0 && K % 32 == 0, "pack_gate_up: need I%%16==0, K%%32==0 (I=%d K=%d)", I, K);
+    long total = (long)(I / 16) * (K / 32) * 64;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t *)gate, (uint4 *)packed, I, K, 2, 0);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t *)up, (uint4 *)packed, I, K, 2, 1);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+// ------------------------------------------------------------------ linear (skinny GEMM, MFMA)
+// Workgroup: NW waves; wave w owns k-steps [w*KSW, (w+1)*KSW) of T consecutive
+// 16-row weight tiles; blockIdx.y selects the 16-token row tile.
+// Variants that keep extra fragments live (fused norm, SwiGLU pair, T == 2) are
+// limited to 8 waves so that they get the 256-VGPR budget.
+template <int KSW, int T, bool SILU, bool NORM>
+__global__ __launch_bounds__((SILU || NORM || T == 2) ? 512 : 1024) void linear_kernel(
+    const bf16_t *__restrict__ x, int ldx, const uint4 *__restrict__ wp, const bf16_t *__restrict__ bias,
+    const bf16_t *__restrict__ res, int ldr, const bf16_t *__restrict__ nw, float eps,
+    bf16_t *__restrict__ out, int ldo, int M, int N, int K) {
+    extern __shared__ float4_t smem4[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int KS = K >> 5;
+    const int m = blockIdx.y * 16 + r;
+    const bool mvalid = m < M;
+    const int ks0 = wave * KSW;
+    const int nt0 = blockIdx.x * T;
+
+    // Weight fragments of the first tile are requested before anything else so
+    // that the HBM latency overlaps the activation prologue.
+    Frag a[T][KSW];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint4 *wptr = wp + ((size_t)(nt0 + t) * KS + ks0) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) a[t][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
+    }
+
+    Frag xb[KSW];
+#pragma unroll
+    for (int i = 0; i < KSW; ++i) {
+        if (mvalid)
+            xb[i].u = *reinterpret_cast<const uint4 *>(x + (size_t)m * ldx + 32 * (ks0 + i) + 8 * g);
+        else
+            xb[i].u = make_uint4(0, 0, 0, 0);
+    }
+
+    float *normred = reinterpret_cast<float *>(smem4 + (size_t)T * NW * 64);
+    if (NORM) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < KSW; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = bf2f(xb[i].h[j]);
+                ss += v * v;
+            }
+        ss += __shfl_xor(ss, 16);
+        ss += __shfl_xor(ss, 32);
+        if (g == 0) normred[wave * 16 + r] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (int w = 0; w < NW; ++w) tot += normred[w * 16 + r];
+        const float rstd = 1.0f / sqrtf(tot / (float)K + eps);
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) {
+            Frag wv;
+            wv.u = *reinterpret_cast<const uint4 *>(nw + 32 * (ks0 + i) + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = rbf(bf2f(xb[i].h[j]) * rstd);
+                xb[i].h[j] = f2bf(v * bf2f(wv.h[j]));
+            }
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KSW; ++i)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][i].v, xb[i].v, acc, 0, 0, 0);
+        smem4[(t * NW + wave) * 64 + lane] = acc;
+    }
+    __syncthreads();
+
+    if (SILU) {
+        // T == 2: tile 0 = gate rows, tile 1 = up rows of the same 16 outputs.
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            float4_t ga = {0.f, 0.f, 0.f, 0.f}, ua = {0.f, 0.f, 0.f, 0.f};
+            for (int w = 0; w < NW; ++w) {
+                ga += smem4[(0 * NW + w) * 64 + l];
+                ua += smem4[(1 * NW + w) * 64 + l];
+            }
+            const int mm = blockIdx.y * 16 + (l & 15);
+            const int n = 16 * blockIdx.x + 4 * (l >> 4);
+            if (mm < M) {
+                bf16_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float gv = rbf(ga[j]);
+                    float uv = rbf(ua[j]);
+                    float s = rbf(gv / (1.0f + expf(-gv)));
+                    o[j] = f2bf(s * uv);
+                }
+                *reinterpret_cast<uint2 *>(out + (size_t)mm * ldo + n) = *reinterpret_cast<uint2 *>(o);
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < 64 * T; e += blockDim.x) {
+            const int t = e >> 6, l = e & 63;
+            float4_t acc = {0.f, 0.f, 0.f, 0.f};
+            for (int w = 0; w < NW; ++w) acc += smem4[(t * NW + w) * 64 + l];
+            const int mm = blockIdx.y * 16 + (l & 15);
+            const int n = 16 * (nt0 + t) + 4 * (l >> 4);
+            if (mm < M) {
+                bf16_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[j];
+                    if (bias) v += bf2f(bias[n + j]);
+                    v = rbf(v);
+                    if (res) v = v + bf2f(res[(size_t)mm * ldr + n + j]);
+                    o[j] = f2bf(v);
+                }
+                *reinterpret_cast<uint2 *>(out + (size_t)mm * ldo + n) = *reinterpret_cast<uint2 *>(o);
+            }
+        }
+    }
+}
+
+static int g_tune_ksw = 0;   // 0 = automatic
+static int g_tune_t = 0;
+extern "C" void qtts_tune_linear(int ksw, int t) { g_tune_ksw = ksw; g_tune_t = t; }
+
+static int pick_ksw(int KS, int max_nw) {
+    static const int prefs[] = {8, 12, 6, 4, 2, 1};
+    if (g_tune_ksw > 0 && KS % g_tune_ksw == 0 && KS / g_tune_ksw <= max_nw) {
+        for (int p : prefs) if (p == g_tune_ksw) return p;
+    }
+    for (int p : prefs)
+        if (KS % p == 0 && KS / p <= max_nw) return p;
+    return 0;
+}
+
+template <int KSW, int T, bool SILU, bool NORM>
+static void launch_linear_inst(dim3 grid, int NW, hipStream_t s, const bf16_t *x, int ldx, const uint4 *wp,
+                               const bf16_t *bias, const bf16_t *res, int ldr, const bf16_t *nw, float eps,
+                               bf16_t *out, int ldo, int M, int N, int K) {
+    size_t shmem = (size_t)T * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
+    hipLaunchKernelGGL((linear_kernel<KSW, T, SILU, NORM>), grid, dim3(NW * 64), shmem, s, x, ldx, wp, bias, res, ldr,
+                       nw, eps, out, ldo, M, N, K);
+}
+
+template <int KSW>
+static void launch_linear_ksw(int T, bool silu, bool norm, dim3 grid, int NW, hipStream_t s, const bf16_t *x, int ldx,
+                              const uint4 *wp, const bf16_t *bias, const bf16_t *res, int ldr, const bf16_t *nw,
+                              float eps, bf16_t *out, int ldo, int M, int N, int K) {
+#define QL(T_, S_, N_) launch_linear_inst<KSW, T_, S_, N_>(grid, NW, s, x, ldx, wp, bias, res, ldr, nw, eps, out, ldo, M, N, K)
+    if (silu) {
+        if (norm) QL(2, true, true); else QL(2, true, false);
+    } else if (T == 2) {
+        if (norm) QL(2, false, true); else QL(2, false, false);
+    } else {
+        if (norm) QL(1, false, true); else QL(1, false, false);
+    }
+#undef QL
+}
+
+static int launch_linear(bool silu, const void *x, int ldx, const void *wp, const void *bias, const void *res, int ldr,
+                         const void *nw, float eps, void *out, int ldo, int M, int N, int K, hipStream_t s) {
+    // N counts packed weight rows (2*I for the gate/up interleave).
+    QCHECK(x && wp && out, "linear: null pointer");
+    QCHECK(M > 0 && N > 0 && K > 0, "linear: empty shape M=%d N=%d K=%d", M, N, K);
+    QCHECK(N % 16 == 0 && K % 32 == 0, "linear: need N%%16==0 and K%%32==0 (N=%d K=%d)", N, K);
+    QCHECK(ldx % 8 == 0 && ldx >= K, "linear: x row stride %d must be a multiple of 8 and >= K", ldx);
+    QCHECK(ldo % 4 == 0, "linear: out row stride %d must be a multiple of 4", ldo);
+    QCHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)wp & 15) == 0 && ((uintptr_t)out & 7) == 0, "linear: misaligned pointer");
+    const int KS = K / 32;
+    const int ntiles = N / 16;
+    int T = 1;
+    if (silu) {
+        QCHECK(ntiles % 2 == 0, "linear_swiglu: odd tile count");
+        T = 2;
+    } else if (g_tune_t == 2 && ntiles % 2 == 0) {
+        T = 2;
+    }
+    const int max_nw = (silu || nw != nullptr || T == 2) ? 8 : 16;
+    const int KSW = pick_ksw(KS, max_nw);
+    QCHECK(KSW > 0, "linear: K=%d cannot be split over <=%d waves", K, max_nw);
+    const int NW = KS / KSW;
+    dim3 grid(ntiles / T, (M + 15) / 16);
+    const bf16_t *xx = (const bf16_t *)x;
+    const uint4 *ww = (const uint4 *)wp;
+#define QK(KSW_) case KSW_: launch_linear_ksw<KSW_>(T, silu, nw != nullptr, grid, NW, s, xx, ldx, ww, (const bf16_t *)bias, \
+        (const bf16_t *)res, ldr, (const bf16_t *)nw, eps, (bf16_t *)out, ldo, M, N, K); break;
+    switch (KSW) {
+        QK(1) QK(2) QK(4) QK(6) QK(8) QK(12)
+        default: QFAIL(QTTS_EINVAL, "linear: unsupported KSW %d", KSW);
+    }
+#undef QK
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+extern "C" int qtts_linear(const void *x, int ldx, const void *w_packed, const void *bias, const void *residual,
+                           int ldr, const void *norm_w, float eps, void *out, int ldo, int M, int N, int K,
+                           qtts_stream_t stream) {
+    if (residual) QCHECK(ldr >= N, "linear: residual row stride %d < N", ldr);
+    QCHECK(ldo >= N, "linear: out row stride %d < N=%d", ldo, N);
+    return launch_linear(false, x, ldx, w_packed, bias, residual, ldr, norm_w, eps, out, ldo, M, N, K,
+                         (hipStream_t)stream);
+}
+
+extern "C" int qtts_linear_swiglu(const void *x, int ldx, const void *w_gate_up_packed, const void *norm_w, float eps,
+                                  void *out, int ldo, int M, int I, int K, qtts_stream_t stream) {
+    QCHECK(ldo >= I, "linear_swiglu: out row stride %d < I=%d", ldo, I);
+    return launch_linear(true, x, ldx, w_gate_up_packed, nullptr, nullptr, 0, norm_w, eps, out, ldo, M, 2 * I, K,
+                         (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ rmsnorm (stand-alone)
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t *__restrict__ x, int ldx, const bf16_t *__restrict__ w,
+                                                      float eps, bf16_t *__restrict__ y, int ldy, int H) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const bf16_t *xr = x + (size_t)row * ldx;
+    float ss = 0.f;
+    for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+        Frag f;
+        f.u = *reinterpret_cast<const uint4 *>(xr + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = bf2f(f.h[j]);
+            ss += v * v;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float rstd = 1.0f / sqrtf(tot / (float)H + eps);
+    for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+        Frag f, wv, o;
+        f.u = *reinterpret_cast<const uint4 *>(xr + i);
+        wv.u = *reinterpret_cast<const uint4 *>(w + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.h[j] = f2bf(rbf(bf2f(f.h[j]) * rstd) * bf2f(wv.h[j]));
+        *reinterpret_cast<uint4 *>(y + (size_t)row * ldy + i) = o.u;
+    }
+}
+
+extern "C" int qtts_rmsnorm(const void *x, int ldx, const void *w, float eps, void *y, int ldy, int M, int H,
+                            qtts_stream_t stream) {
+    QCHECK(x && w && y, "rmsnorm: null pointer");
+    QCHECK(M > 0 && H > 0 && H % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= H && ldy >= H,
+           "rmsnorm: bad shape M=%d H=%d ldx=%d ldy=%d", M, H, ldx, ldy);
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, ldx,
+                       (const bf16_t *)w, eps, (bf16_t *)y, ldy, H);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+// ------------------------------------------------------------------ q/k norm + RoPE + KV store
+// One wave per (token, head); lane i owns dims i and i+64 (the rotate_half pair).
+__global__ __launch_bounds__(64) void qknorm_rope_store_kernel(
+    bf16_t *__restrict__ qkv, int ld, const bf16_t *__restrict__ qw, const bf16_t *__restrict__ kw, float eps,
+    const bf16_t *__restrict__ cosT, const bf16_t *__restrict__ sinT, const int64_t *__restrict__ positions,
+    const int32_t *__restrict__ slots, bf16_t *__restrict__ kc, bf16_t *__restrict__ vc, int Hq, int Hkv) {
+    const int tok = blockIdx.x, head = blockIdx.y, i = threadIdx.x;
+    bf16_t *p = qkv + (size_t)tok * ld + (size_t)head * 128;
+    const int slot = slots ? slots[tok] : -1;
+    if (head >= Hq + Hkv) {                        // value head: cache copy only
+        if (vc && slot >= 0) {
+            bf16_t *dst = vc + ((size_t)slot * Hkv + (head - Hq - Hkv)) * 128;
+            dst[i] = p[i];
+            dst[i + 64] = p[i + 64];
+        }
+        return;
+    }
+    const bool isq = head < Hq;
+    const bf16_t *w = isq ? qw : kw;
+    const float x0 = bf2f(p[i]), x1 = bf2f(p[i + 64]);
+    float ss = x0 * x0 + x1 * x1;
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rstd = 1.0f / sqrtf(ss / 128.0f + eps);
+    const float n0 = rbf(rbf(x0 * rstd) * bf2f(w[i]));
+    const float n1 = rbf(rbf(x1 * rstd) * bf2f(w[i + 64]));
+    const long pos = positions[tok];
+    const float c = bf2f(cosT[pos * 64 + i]), s = bf2f(sinT[pos * 64 + i]);
+    // q*cos + rotate_half(q)*sin, each op rounded to bf16
+    const bf16_t o0 = f2bf(rbf(n0 * c) + rbf(-n1 * s));
+    const bf16_t o1 = f2bf(rbf(n1 * c) + rbf(n0 * s));
+    p[i] = o0;
+    p[i + 64] = o1;
+    if (!isq && kc && slot >= 0) {
+        bf16_t *dst = kc + ((size_t)slot * Hkv + (head - Hq)) * 128;
+        dst[i] = o0;
+        dst[i + 64] = o1;
+    }
+}
+
+extern "C" int qtts_qknorm_rope_store(void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w, float eps,
+                                      const void *rope_cos, const void *rope_sin, int max_pos,
+                                      const int64_t *positions, const int32_t *slot_mapping, void *k_cache,
+                                      void *v_cache, int N, int Hq, int Hkv, qtts_stream_t stream) {
+    QCHECK(qkv && q_norm_w && k_norm_w && rope_cos && rope_sin && positions, "qknorm_rope_store: null pointer");
+    QCHECK(N > 0 && Hq > 0 && Hkv > 0 && ldqkv >= (Hq + 2 * Hkv) * 128, "qknorm_rope_store: bad shape");
+    QCHECK(max_pos > 0, "qknorm_rope_store: empty rope table");
+    hipLaunchKernelGGL(qknorm_rope_store_kernel, dim3(N, Hq + 2 * Hkv), dim3(64), 0, (hipStream_t)stream,
+                       (bf16_t *)qkv, ldqkv, (const bf16_t *)q_norm_w, (const bf16_t *)k_norm_w, eps,
+                       (const bf16_t *)rope_cos, (const bf16_t *)rope_sin, positions, slot_mapping, (bf16_t *)k_cache,
+                       (bf16_t *)v_cache, Hq, Hkv);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+__global__ __launch_bounds__(128) void store_kvcache_kernel(const bf16_t *__restrict__ k, int ldk,
+                                                            const bf16_t *__restrict__ v, int ldv,
+                                                            bf16_t *__restrict__ kc, bf16_t *__restrict__ vc,
+                                                            const int32_t *__restrict__ slots, int D) {
+    const int tok = blockIdx.x;
+    const int slot = slots[tok];
+    if (slot < 0) return;
+    for (int i = threadIdx.x * 8; i < D; i += 128 * 8) {
+        *reinterpret_cast<uint4 *>(kc + (size_t)slot * D + i) = *reinterpret_cast<const uint4 *>(k + (size_t)tok * ldk + i);
+        *reinterpret_cast<uint4 *>(vc + (size_t)slot * D + i) = *reinterpret_cast<const uint4 *>(v + (size_t)tok * ldv + i);
+    }
+}
+
+extern "C" int qtts_store_kvcache(const void *k, int ldk, const void *v, int ldv, void *k_cache, void *v_cache,
+                                  const int32_t *slot_mapping, int N, int Hkv, qtts_stream_t stream) {
+    QCHECK(k && v && k_cache && v_cache && slot_mapping, "store_kvcache: null pointer");
+    QCHECK(N > 0 && Hkv > 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldk >= Hkv * 128 && ldv >= Hkv * 128,
+           "store_kvcache: bad shape");
+    hipLaunchKernelGGL(store_kvcache_kernel, dim3(N), dim3(128), 0, (hipStream_t)stream, (const bf16_t *)k, ldk,
+                       (const bf16_t *)v, ldv, (bf16_t *)k_cache, (bf16_t *)v_cache, slot_mapping, Hkv * 128);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+// ------------------------------------------------------------------ paged attention
+#define ATT_SPLIT 128   // tokens per workgroup
+// grid (rows, Hkv, nsplit); 256 threads = 16 groups of 16 lanes; a group owns
+// tokens split*128 + i*16 + grp, i < 8; a lane owns 8 of the 128 head dims.
+template <int G>
+__global__ __launch_bounds__(256) void paged_attn_kernel(
+    const bf16_t *__restrict__ q, int ldq, const bf16_t *__restrict__ kc, const bf16_t *__restrict__ vc,
+    const int32_t *__restrict__ block_tables, int max_blocks, const int32_t *__restrict__ row_seq,
+    const int32_t *__restrict__ context_lens, float scale, bf16_t *__restrict__ out, int ldo, int Hkv,
+    float *__restrict__ part_o, float *__restrict__ part_ml, int nsplit) {
+    __shared__ float sm_acc[16][G][128];
+    __shared__ float sm_m[16][G];
+    __shared__ float sm_l[16][G];
+    const int row = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
+    const int ctx = context_lens[row];
+    const int Hq = Hkv * G;
+    const int t0 = split * ATT_SPLIT;
+    if (ctx <= 0) {
+        if (split == 0 && nsplit == 1)
+            for (int e = threadIdx.x; e < G * 128; e += 256) out[(size_t)row * ldo + (size_t)kvh * G * 128 + e] = 0;
+        return;
+    }
+    if (t0 >= ctx) return;
+    const int seq = row_seq ? row_seq[row] : row;
+    const int32_t *bt = block_tables + (size_t)seq * max_blocks;
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+
+    Frag kk[8], vv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int t = t0 + i * 16 + grp;
+        if (t < ctx) {
+            const int blk = bt[t >> 8];
+            const size_t base = (((size_t)blk * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
+            kk[i].u = *reinterpret_cast<const uint4 *>(kc + base);
+            vv[i].u = *reinterpret_cast<const uint4 *>(vc + base);
+        } else {
+            kk[i].u = make_uint4(0, 0, 0, 0);
+            vv[i].u = make_uint4(0, 0, 0, 0);
+        }
+    }
+    float qf[G][8];
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+        Frag f;
+        f.u = *reinterpret_cast<const uint4 *>(q + (size_t)row * ldq + (size_t)(kvh * G + h) * 128 + 8 * l16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[h][j] = bf2f(f.h[j]);
+    }
+    float mx[G], ls[G], acc[G][8];
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+        mx[h] = -INFINITY;
+        ls[h] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int t = t0 + i * 16 + grp;
+        const bool valid = t < ctx;                 // uniform within a 16-lane group
+        float kf[8], vf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            kf[j] = bf2f(kk[i].h[j]);
+            vf[j] = bf2f(vv[i].h[j]);
+        }
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += qf[h][j] * kf[j];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 8);
+            s *= scale;
+            if (valid) {
+                const float mn = fmaxf(mx[h], s);
+                const float corr = __expf(mx[h] - mn);
+                const float p = __expf(s - mn);
+                ls[h] = ls[h] * corr + p;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[h][j] = acc[h][j] * corr + p * vf[j];
+                mx[h] = mn;
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sm_acc[grp][h][8 * l16 + j] = acc[h][j];
+        if (l16 == 0) {
+            sm_m[grp][h] = mx[h];
+            sm_l[grp][h] = ls[h];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < G * 128; e += 256) {
+        const int h = e >> 7, d = e & 127;
+        float M = -INFINITY;
+#pragma unroll
+        for (int gI = 0; gI < 16; ++gI) M = fmaxf(M, sm_m[gI][h]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int gI = 0; gI < 16; ++gI) {
+            const float wgt = __expf(sm_m[gI][h] - M);      // exp(-inf) = 0 for empty groups
+            L += sm_l[gI][h] * wgt;
+            o += sm_acc[gI][h][d] * wgt;
+        }
+        const int hq = kvh * G + h;
+        if (nsplit == 1) {
+            out[(size_t)row * ldo + (size_t)hq * 128 + d] = f2bf(o / L);
+        } else {
+            const size_t pi = ((size_t)row * Hq + hq) * nsplit + split;
+            part_o[pi * 128 + d] = o;
+            if (d == 0) {
+                part_ml[pi * 2 + 0] = M;
+                part_ml[pi * 2 + 1] = L;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void attn_combine_kernel(const float *__restrict__ part_o,
+                                                           const float *__restrict__ part_ml,
+                                                           const int32_t *__restrict__ context_lens,
+                                                           bf16_t *__restrict__ out, int ldo, int Hq, int nsplit) {
+    const int row = blockIdx.x, hq = blockIdx.y, d = threadIdx.x;
+    const int ctx = context_lens[row];
+    if (ctx <= 0) {
+        out[(size_t)row * ldo + (size_t)hq * 128 + d] = 0;
+        return;
+    }
+    const int ns = (ctx + ATT_SPLIT - 1) / ATT_SPLIT;
+    const size_t p0 = ((size_t)row * Hq + hq) * nsplit;
+    float M = -INFINITY;
+    for (int s = 0; s < ns; ++s) M = fmaxf(M, part_ml[(p0 + s) * 2]);
+    float L = 0.f, o = 0.f;
+    for (int s = 0; s < ns; ++s) {
+        const float wgt = __expf(part_ml[(p0 + s) * 2] - M);
+        L += part_ml[(p0 + s) * 2 + 1] * wgt;
+        o += part_o[(p0 + s) * 128 + d] * wgt;
+    }
+    out[(size_t)row * ldo + (size_t)hq * 128 + d] = f2bf(o / L);
+}
+
+static inline int attn_nsplit(int max_context) { return max_context <= ATT_SPLIT ? 1 : (max_context + ATT_SPLIT - 1) / ATT_SPLIT; }
+
+extern "C" size_t qtts_attn_workspace_bytes(int N, int Hq, int max_context) {
+    int ns = attn_nsplit(max_context);
+    if (ns == 1) return 256;
+    return (size_t)N * Hq * ns * (128 + 2) * sizeof(float) + 256;
+}
+
+extern "C" int qtts_paged_attention(const void *q, int ldq, const void *k_cache, const void *v_cache,
+                                    const int32_t *block_tables, int max_blocks, const int32_t *row_seq,
+                                    const int32_t *context_lens, int max_context, float scale, void *out, int ldo,
+                                    int N, int Hq, int Hkv, void *workspace, qtts_stream_t stream) {
+    QCHECK(q && k_cache && v_cache && block_tables && context_lens && out, "paged_attention: null pointer");
+    QCHECK(N > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "paged_attention: bad head counts %d/%d", Hq, Hkv);
+    QCHECK(ldq % 8 == 0 && ldq >= Hq * 128 && ldo >= Hq * 128, "paged_attention: bad strides");
+    QCHECK(max_blocks > 0 && max_context > 0 && max_context <= max_blocks * QTTS_KV_BLOCK,
+           "paged_attention: max_context %d exceeds %d blocks", max_context, max_blocks);
+    const int G = Hq / Hkv;
+    const int ns = attn_nsplit(max_context);
+    QCHECK(ns == 1 || workspace, "paged_attention: workspace required for contexts > %d", ATT_SPLIT);
+    float *part_o = (float *)workspace;
+    float *part_ml = part_o ? part_o + (size_t)N * Hq * ns * 128 : nullptr;
+    dim3 grid(N, Hkv, ns);
+    hipStream_t s = (hipStream_t)stream;
+#define QA(G_) case G_: hipLaunchKernelGGL((paged_attn_kernel<G_>), grid, dim3(256), 0, s, (const bf16_t *)q, ldq, \
+        (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq, context_lens, scale, \
+        (bf16_t *)out, ldo, Hkv, part_o, part_ml, ns); break;
+    switch (G) {
+        QA(1) QA(2) QA(4)
+        default: QFAIL(QTTS_EINVAL, "paged_attention: unsupported q/kv head ratio %d", G);
+    }
+#undef QA
+    QLAUNCH();
+    if (ns > 1) {
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(N, Hq), dim3(128), 0, s, part_o, part_ml, context_lens,
+                           (bf16_t *)out, ldo, Hq, ns);
+        QLAUNCH();
+    }
+    return QTTS_OK;
+}
+
+// ------------------------------------------------------------------ sampling
+__global__ __launch_bounds__(256) void argmax_kernel(const bf16_t *__restrict__ logits, int ld, int64_t *__restrict__ out, int ldout, int V) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int row = blockIdx.x;
+    const bf16_t *p = logits + (size_t)row * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += 256) {
+        float v = bf2f(p[i]);
+        if (v > best || (v == best && i < bi)) {
+            best = v;
+            bi = i;
+        }
+    }
+    if (bi == 0x7fffffff && threadIdx.x < V) bi = threadIdx.x;   // all -inf / NaN rows
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o);
+        int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sv[threadIdx.x >> 6] = best;
+        si[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+                best = sv[w];
+                bi = si[w];
+            }
+        out[(size_t)row * ldout] = bi;
+    }
+}
+
+extern "C" int qtts_argmax(const void *logits, int ld, int64_t *out, int M, int V, qtts_stream_t stream) {
+    QCHECK(logits && out && M > 0 && V > 0 && ld >= V, "argmax: bad arguments");
+    hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)logits, ld, out, 1, V);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+// splitmix64-based counter RNG: uniform in [0,1)
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t offset, uint64_t row) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (offset * 0x100000001B3ull + row + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// One workgroup per row; V <= 4096 values staged in LDS.
+__global__ __launch_bounds__(256) void sample_topk_kernel(const bf16_t *__restrict__ logits, int ld,
+                                                          const float *__restrict__ temps, int top_k, uint64_t seed,
+                                                          uint64_t offset, const uint64_t *__restrict__ offset_dev,
+                                                          const uint8_t *__restrict__ greedy, int64_t *__restrict__ out,
+                                                          int ldout, int V) {
+    __shared__ float val[4096];
+    __shared__ float wv[4];
+    __shared__ int wi[4];
+    __shared__ float kth_s;
+    const int row = blockIdx.x;
+    const bool is_greedy = greedy && greedy[row];
+    const float T = is_greedy ? 1.0f : temps[row];
+    if (is_greedy) top_k = 1;            // round 0 below is exactly argmax with the lowest index on ties
+    if (offset_dev) offset += *offset_dev;
+    for (int i = threadIdx.x; i < V; i += 256) val[i] = bf2f(logits[(size_t)row * ld + i]) / T;
+    __syncthreads();
+    // k-th largest by k rounds of "largest value strictly below the previous one / next duplicate".
+    // Values are compared with (value, index) order so duplicates are counted one by one.
+    float prev_v = INFINITY;
+    int prev_i = -1;
+    float maxv = -INFINITY;
+    for (int k = 0; k < top_k; ++k) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = threadIdx.x; i < V; i += 256) {
+            float v = val[i];
+            bool after_prev = (v < prev_v) || (v == prev_v && i > prev_i);
+            if (after_prev && (v > best || (v == best && i < bi))) {
+                best = v;
+                bi = i;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(best, o);
+            int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        if ((threadIdx.x & 63) == 0) {
+            wv[threadIdx.x >> 6] = best;
+            wi[threadIdx.x >> 6] = bi;
+        }
+        __syncthreads();
+        best = wv[0];
+        bi = wi[0];
+        for (int w = 1; w < 4; ++w)
+            if (wv[w] > best || (wv[w] == best && wi[w] < bi)) {
+                best = wv[w];
+                bi = wi[w];
+            }
+        __syncthreads();
+        prev_v = best;
+        prev_i = bi;
+        if (k == 0) maxv = best;
+    }
+    if (is_greedy) {
+        if (threadIdx.x == 0) out[(size_t)row * ldout] = prev_i;
+        return;
+    }
+    const float kth = prev_v;
+    // softmax over values >= kth (ties at the threshold are all kept, as `logits < kth` removes only smaller ones)
+    float part = 0.f;
+    for (int i = threadIdx.x; i < V; i += 256) {
+        float v = val[i];
+        float p = (v >= kth) ? __expf(v - maxv) : 0.f;
+        val[i] = p;
+        part += p;
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((threadIdx.x & 63) == 0) wv[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = wv[0] + wv[1] + wv[2] + wv[3];
+        const float u = rng_uniform(seed, offset, row) * total;
+        float c = 0.f;
+        int pick = -1, lastnz = 0;
+        for (int i = 0; i < V; ++i) {
+            float p = val[i];
+            if (p > 0.f) {
+                lastnz = i;
+                c += p;
+                if (c > u) {
+                    pick = i;
+                    break;
+                }
+            }
+        }
+        out[(size_t)row * ldout] = pick >= 0 ? pick : lastnz;
+    }
+}
+
+extern "C" int qtts_pick_token(const void *logits, int ld, const float *temperatures, const uint8_t *greedy_flags,
+                               int top_k, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, int64_t *out,
+                               int ldout, int M, int V, qtts_stream_t stream) {
+    QCHECK(logits && temperatures && out && M > 0 && V > 0 && ld >= V && ldout >= 1, "pick_token: bad arguments");
+    QCHECK(V <= 4096, "pick_token: V=%d > 4096", V);
+    QCHECK(top_k >= 1 && top_k <= V, "pick_token: top_k=%d out of range", top_k);
+    hipLaunchKernelGGL(sample_topk_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)logits, ld,
+                       temperatures, top_k, seed, offset, offset_dev, greedy_flags, out, ldout, V);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+extern "C" int qtts_sample_topk(const void *logits, int ld, const float *temperatures, int top_k, uint64_t seed,
+                                uint64_t offset, int64_t *out, int M, int V, qtts_stream_t stream) {
+    return qtts_pick_token(logits, ld, temperatures, nullptr, top_k, seed, offset, nullptr, out, 1, M, V, stream);
+}
+
+// ------------------------------------------------------------------ gathers / frame glue
+__global__ __launch_bounds__(256) void embedding_gather_kernel(const bf16_t *__restrict__ table,
+                                                               const int64_t *__restrict__ ids,
+                                                               bf16_t *__restrict__ out, int ldo, int H, int vocab) {
+    const int row = blockIdx.x;
+    long id = ids[row];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    for (int i = threadIdx.x * 8; i < H; i += 256 * 8)
+        *reinterpret_cast<uint4 *>(out + (size_t)row * ldo + i) = *reinterpret_cast<const uint4 *>(table + (size_t)id * H + i);
+}
+
+extern "C" int qtts_embedding_gather(const void *table, const int64_t *ids, void *out, int ldo, int M, int H, int vocab,
+                                     qtts_stream_t stream) {
+    QCHECK(table && ids && out && M > 0 && H > 0 && H % 8 == 0 && ldo % 8 == 0 && ldo >= H && vocab > 0,
+           "embedding_gather: bad arguments");
+    hipLaunchKernelGGL(embedding_gather_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)table, ids,
+                       (bf16_t *)out, ldo, H, vocab);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+__global__ __launch_bounds__(256) void predictor_input_kernel(const bf16_t *__restrict__ hidden,
+                                                              const bf16_t *__restrict__ emb,
+                                                              const int64_t *__restrict__ tok,
+                                                              bf16_t *__restrict__ out, int H, int vocab) {
+    const int b = blockIdx.x;
+    long id = tok[b];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
+        *reinterpret_cast<uint4 *>(out + ((size_t)b * 2 + 0) * H + i) = *reinterpret_cast<const uint4 *>(hidden + (size_t)b * H + i);
+        *reinterpret_cast<uint4 *>(out + ((size_t)b * 2 + 1) * H + i) = *reinterpret_cast<const uint4 *>(emb + (size_t)id * H + i);
+    }
+}
+
+extern "C" int qtts_predictor_input(const void *hidden, const void *talker_emb, const int64_t *token0, void *pred_in,
+                                    int B, int H, int vocab, qtts_stream_t stream) {
+    QCHECK(hidden && talker_emb && token0 && pred_in && B > 0 && H > 0 && H % 8 == 0 && vocab > 0,
+           "predictor_input: bad arguments");
+    hipLaunchKernelGGL(predictor_input_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)hidden,
+                       (const bf16_t *)talker_emb, token0, (bf16_t *)pred_in, H, vocab);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+// Sum order follows torch's CPU reduction over the 16 stacked rows (sequential, row 0 first).
+__global__ __launch_bounds__(256) void frame_glue_kernel(const bf16_t *__restrict__ temb,
+                                                         const bf16_t *const *__restrict__ ptabs,
+                                                         const int64_t *__restrict__ codes,
+                                                         const float *__restrict__ text_add,
+                                                         bf16_t *__restrict__ next, int H, int tv, int pv) {
+    const int b = blockIdx.x;
+    for (int d = threadIdx.x; d < H; d += 256) {
+        long c0 = codes[b * 16];
+        c0 = c0 < 0 ? 0 : (c0 >= tv ? tv - 1 : c0);
+        float s = bf2f(temb[(size_t)c0 * H + d]);
+        for (int c = 1; c < 16; ++c) {
+            long id = codes[b * 16 + c];
+            id = id < 0 ? 0 : (id >= pv ? pv - 1 : id);
+            s += bf2f(ptabs[c - 1][(size_t)id * H + d]);
+        }
+        next[(size_t)b * H + d] = f2bf(s + text_add[(size_t)b * H + d]);
+    }
+}
+
+extern "C" int qtts_frame_glue(const void *talker_emb, const void *const *pred_emb_tables, const int64_t *codes,
+                               const float *text_add, void *next, int B, int H, int talker_vocab, int pred_vocab,
+                               qtts_stream_t stream) {
+    QCHECK(talker_emb && pred_emb_tables && codes && text_add && next && B > 0 && H > 0, "frame_glue: bad arguments");
+    hipLaunchKernelGGL(frame_glue_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)talker_emb,
+                       (const bf16_t *const *)pred_emb_tables, codes, text_add, (bf16_t *)next, H, talker_vocab,
+                       pred_vocab);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+// ------------------------------------------------------------------ decoder stack
+struct LayerW {
+    const void *in_norm = nullptr, *wqkv = nullptr, *q_norm = nullptr, *k_norm = nullptr, *wo = nullptr,
+               *post_norm = nullptr, *wgu = nullptr, *wdown = nullptr;
+};
+
+struct qtts_model {
+    int hidden, n_layers, n_heads, n_kv_heads, head_dim, inter;
+    float eps;
+    std::vector<LayerW> layers;
+    const void *final_norm = nullptr;
+    const void *cosT = nullptr, *sinT = nullptr;
+    int max_pos = 0;
+    char *kv = nullptr;
+    int num_blocks = 0;
+    char *ws = nullptr;
+    size_t ws_bytes = 0;
+    int ws_rows = 0, ws_ctx = 0;
+};
+
+extern "C" qtts_model_t *qtts_model_create(int hidden, int n_layers, int n_heads, int n_kv_heads, int head_dim,
+                                           int intermediate, float rms_eps) {
+    if (hidden <= 0 || n_layers <= 0 || n_heads <= 0 || n_kv_heads <= 0 || intermediate <= 0 ||
+        head_dim != QTTS_HEAD_DIM || n_heads % n_kv_heads != 0 || hidden % 32 != 0 || intermediate % 32 != 0) {
+        snprintf(g_err, sizeof(g_err), "model_create: unsupported shape (head_dim must be 128, sizes multiples of 32)");
+        return nullptr;
+    }
+    qtts_model *m = new qtts_model();
+    m->hidden = hidden;
+    m->n_layers = n_layers;
+    m->n_heads = n_heads;
+    m->n_kv_heads = n_kv_heads;
+    m->head_dim = head_dim;
+    m->inter = intermediate;
+    m->eps = rms_eps;
+    m->layers.resize(n_layers);
+    return m;
+}
+
+extern "C" void qtts_model_destroy(qtts_model_t *m) { delete m; }
+
+extern "C" int qtts_model_set_layer(qtts_model_t *m, int layer, const void *input_norm_w, const void *wqkv_packed,
+                                    const void *q_norm_w, const void *k_norm_w, const void *wo_packed,
+                                    const void *post_norm_w, const void *w_gate_up_packed, const void *w_down_packed) {
+    QCHECK(m && layer >= 0 && layer < m->n_layers, "model_set_layer: bad layer index");
+    QCHECK(input_norm_w && wqkv_packed && q_norm_w && k_norm_w && wo_packed && post_norm_w && w_gate_up_packed &&
+               w_down_packed, "model_set_layer: null weight");
+    LayerW &L = m->layers[layer];
+    L.in_norm = input_norm_w;
+    L.wqkv = wqkv_packed;
+    L.q_norm = q_norm_w;
+    L.k_norm = k_norm_w;
+    L.wo = wo_packed;
+    L.post_norm = post_norm_w;
+    L.wgu = w_gate_up_packed;
+    L.wdown = w_down_packed;
+    return QTTS_OK;
+}
+
+extern "C" int qtts_model_set_final_norm(qtts_model_t *m, const void *w) {
+    QCHECK(m && w, "model_set_final_norm: null");
+    m->final_norm = w;
+    return QTTS_OK;
+}
+
+extern "C" int qtts_model_set_rope(qtts_model_t *m, const void *cos, const void *sin, int max_pos) {
+    QCHECK(m && cos && sin && max_pos > 0, "model_set_rope: bad arguments");
+    m->cosT = cos;
+    m->sinT = sin;
+    m->max_pos = max_pos;
+    return QTTS_OK;
+}
+
+extern "C" int qtts_model_set_kv_cache(qtts_model_t *m, void *kv, int num_blocks) {
+    QCHECK(m && kv && num_blocks > 0, "model_set_kv_cache: bad arguments");
+    m->kv = (char *)kv;
+    m->num_blocks = num_blocks;
+    return QTTS_OK;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct WsLayout {
+    size_t qkv, attn, act, xa, xb, att_ws, total;
+};
+
+static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
+    WsLayout L;
+    size_t off = 0;
+    const size_t qkvw = (size_t)(m->n_heads + 2 * m->n_kv_heads) * 128;
+    L.qkv = off; off += align256((size_t)rows * qkvw * 2);
+    L.attn = off; off += align256((size_t)rows * m->n_heads * 128 * 2);
+    L.act = off; off += align256((size_t)rows * m->inter * 2);
+    L.xa = off; off += align256((size_t)rows * m->hidden * 2);
+    L.xb = off; off += align256((size_t)rows * m->hidden * 2);
+    L.att_ws = off; off += align256(qtts_attn_workspace_bytes(rows, m->n_heads, max_context));
+    L.total = off;
+    return L;
+}
+
+extern "C" size_t qtts_model_workspace_bytes(const qtts_model_t *m, int max_rows, int max_context) {
+    if (!m || max_rows <= 0 || max_context <= 0) return 0;
+    return ws_layout(m, max_rows, max_context).total;
+}
+
+extern "C" int qtts_model_set_workspace(qtts_model_t *m, void *ws, size_t bytes, int max_rows, int max_context) {
+    QCHECK(m && ws && max_rows > 0 && max_context > 0, "model_set_workspace: bad arguments");
+    QCHECK(((uintptr_t)ws & 255) == 0, "model_set_workspace: workspace must be 256-byte aligned");
+    QCHECK(bytes >= ws_layout(m, max_rows, max_context).total, "model_set_workspace: %zu bytes < required %zu", bytes,
+           ws_layout(m, max_rows, max_context).total);
+    m->ws = (char *)ws;
+    m->ws_bytes = bytes;
+    m->ws_rows = max_rows;
+    m->ws_ctx = max_context;
+    return QTTS_OK;
+}
+
+extern "C" int qtts_model_forward(qtts_model_t *m, const void *x, const int64_t *positions, const int32_t *slot_mapping,
+                                  const int32_t *row_seq, const int32_t *context_lens, const int32_t *block_tables,
+                                  int max_blocks, int max_context, int N, void *hidden_out, qtts_stream_t stream) {
+    QCHECK(m, "model_forward: null model");
+    if (!m->final_norm || !m->cosT || !m->kv || !m->ws) QFAIL(QTTS_ESTATE, "model_forward: model not fully configured");
+    for (const LayerW &L : m->layers)
+        if (!L.wqkv) QFAIL(QTTS_ESTATE, "model_forward: layer weights missing");
+    QCHECK(x && positions && context_lens && block_tables && hidden_out, "model_forward: null pointer");
+    QCHECK(N > 0 && N <= m->ws_rows, "model_forward: N=%d exceeds workspace rows %d", N, m->ws_rows);
+    QCHECK(max_context > 0 && max_context <= m->ws_ctx, "model_forward: max_context=%d exceeds workspace %d", max_context, m->ws_ctx);
+    QCHECK(max_blocks > 0 && max_context <= max_blocks * QTTS_KV_BLOCK, "model_forward: max_context exceeds block table");
+    const WsLayout W = ws_layout(m, m->ws_rows, m->ws_ctx);
+    bf16_t *qkv = (bf16_t *)(m->ws + W.qkv);
+    bf16_t *attn = (bf16_t *)(m->ws + W.attn);
+    bf16_t *act = (bf16_t *)(m->ws + W.act);
+    bf16_t *xa = (bf16_t *)(m->ws + W.xa);
+    bf16_t *xb = (bf16_t *)(m->ws + W.xb);
+    void *att_ws = m->ws + W.att_ws;
+    const int H = m->hidden, Hq = m->n_heads, Hkv = m->n_kv_heads;
+    const int qkvw = (Hq + 2 * Hkv) * 128;
+    const float scale = 1.0f / sqrtf((float)m->head_dim);
+    const size_t layer_kv = (size_t)m->num_blocks * QTTS_KV_BLOCK * Hkv * 128 * 2;   // bytes per layer per K or V
+    const bf16_t *cur = (const bf16_t *)x;
+    int rc;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const LayerW &L = m->layers[l];
+        char *kc = m->kv + (size_t)l * layer_kv;
+        char *vc = m->kv + ((size_t)m->n_layers + l) * layer_kv;
+        if ((rc = qtts_linear(cur, H, L.wqkv, nullptr, nullptr, 0, L.in_norm, m->eps, qkv, qkvw, N, qkvw, H, stream))) return rc;
+        if ((rc = qtts_qknorm_rope_store(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos, positions,
+                                         slot_mapping, kc, vc, N, Hq, Hkv, stream))) return rc;
+        if ((rc = qtts_paged_attention(qkv, qkvw, kc, vc, block_tables, max_blocks, row_seq, context_lens, max_context,
+                                       scale, attn, Hq * 128, N, Hq, Hkv, att_ws, stream))) return rc;
+        if ((rc = qtts_linear(attn, Hq * 128, L.wo, nullptr, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, stream))) return rc;
+        if ((rc = qtts_linear_swiglu(xa, H, L.wgu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
+        if ((rc = qtts_linear(act, m->inter, L.wdown, nullptr, xa, H, nullptr, 0.f, xb, H, N, H, m->inter, stream))) return rc;
+        // Fixed roles: xa = post-attention residual stream, xb = layer output.  The next layer reads xb
+        // (qkv GEMM, o_proj residual) before its down_proj overwrites it, all stream-ordered.
+        cur = xb;
+    }
+    if ((rc = qtts_rmsnorm(cur, H, m->final_norm, m->eps, hidden_out, H, N, H, stream))) return rc;
+    return QTTS_OK;
+}
+
+// ------------------------------------------------------------------ hipGraph helpers
+struct qtts_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int qtts_graph_begin(qtts_stream_t stream) {
+    hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) QFAIL((int)e, "graph_begin: %s", hipGetErrorString(e));
+    return QTTS_OK;
+}
+
+extern "C" qtts_graph_t *qtts_graph_end(qtts_stream_t stream) {
+    qtts_graph *g = new qtts_graph();
+    hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g->graph);
+    if (e != hipSuccess || !g->graph) {
+        snprintf(g_err, sizeof(g_err), "graph_end: %s", hipGetErrorString(e));
+        delete g;
+        return nullptr;
+    }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "graph_instantiate: %s", hipGetErrorString(e));
+        (void)hipGraphDestroy(g->graph);
+        delete g;
+        return nullptr;
+    }
+    return g;
+}
+
+extern "C" int qtts_graph_launch(qtts_graph_t *g, qtts_stream_t stream) {
+    QCHECK(g && g->exec, "graph_launch: null graph");
+    hipError_t e = hipGraphLaunch(g->exec, (hipStream_t)stream);
+    if (e != hipSuccess) QFAIL((int)e, "graph_launch: %s", hipGetErrorString(e));
+    return QTTS_OK;
+}
+
+extern "C" void qtts_graph_destroy(qtts_graph_t *g) {
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}

@@ -1,0 +1,120 @@
+"""Device-resident decoder stack: weights packed for the HIP kernels, paged KV
+cache and workspace owned here, one C-ABI call per forward.
+
+Replaces the nn.Module stacks of the reference
+(P/models/qwen3_tts_talker.py:34-62, P/models/qwen3_tts_predictor.py:17-44,
+layer body P/models/qwen3_tts_share.py:13-176) and the KV allocation of
+P/engine/model_runner/base.py:131-164.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from .. import hip
+
+BLOCK = 256
+
+
+@dataclass
+class DecoderShape:
+    hidden_size: int
+    num_layers: int
+    num_heads: int
+    num_kv_heads: int
+    head_dim: int
+    intermediate_size: int
+    rms_eps: float = 1e-6
+    rope_theta: float = 10000.0
+
+    @staticmethod
+    def from_config(c: dict) -> "DecoderShape":
+        hd = c.get("head_dim") or c["hidden_size"] // c["num_attention_heads"]
+        return DecoderShape(c["hidden_size"], c["num_hidden_layers"], c["num_attention_heads"],
+                            c["num_key_value_heads"], hd, c["intermediate_size"],
+                            c.get("rms_norm_eps", 1e-6), c.get("rope_theta", 10000.0))
+
+
+def rope_tables(head_dim: int, theta: float, max_pos: int):
+    """bf16 cos/sin [max_pos, head_dim/2], computed on the host in fp32 exactly as
+    P/layers/rotary_embedding.py:98,134-139 does (the runners only pass 1-D positions,
+    so the talker's three M-RoPE rows are equal and reduce to this table)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    freqs = torch.arange(max_pos, dtype=torch.int64).float()[:, None] * inv_freq[None, :]
+    return freqs.cos().to(torch.bfloat16), freqs.sin().to(torch.bfloat16)
+
+
+class HipDecoder:
+    def __init__(self, weights: dict, shape: DecoderShape, num_kv_blocks: int, max_rows: int,
+                 max_context: int = 1024, device="cuda", max_pos: int = 2048, prefix: str = "model."):
+        self.shape = s = shape
+        self.device = torch.device(device)
+        self.max_rows, self.max_context, self.max_pos = max_rows, max_context, max_pos
+        self.num_kv_blocks = num_kv_blocks
+        self._keep = []          # device tensors the C side points into
+
+        def dev(t):
+            t = t.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            self._keep.append(t)
+            return t
+
+        h = hip.lib.qtts_model_create(s.hidden_size, s.num_layers, s.num_heads, s.num_kv_heads, s.head_dim,
+                                      s.intermediate_size, s.rms_eps)
+        if not h:
+            raise hip.QttsError("model_create: " + hip.lib.qtts_last_error().decode())
+        self._h = h
+        for i in range(s.num_layers):
+            p = f"{prefix}layers.{i}."
+            wqkv = torch.cat([weights[p + "self_attn.q_proj.weight"], weights[p + "self_attn.k_proj.weight"],
+                              weights[p + "self_attn.v_proj.weight"]], 0)
+            wqkv_p = hip.pack_weight(dev(wqkv))
+            wo_p = hip.pack_weight(dev(weights[p + "self_attn.o_proj.weight"]))
+            wgu_p = hip.pack_gate_up(dev(weights[p + "mlp.gate_proj.weight"]), dev(weights[p + "mlp.up_proj.weight"]))
+            wd_p = hip.pack_weight(dev(weights[p + "mlp.down_proj.weight"]))
+            torch.cuda.synchronize()
+            del self._keep[-5:]          # row-major copies are no longer needed once packed
+            tensors = [dev(weights[p + "input_layernorm.weight"]), wqkv_p, dev(weights[p + "self_attn.q_norm.weight"]),
+                       dev(weights[p + "self_attn.k_norm.weight"]), wo_p, dev(weights[p + "post_attention_layernorm.weight"]),
+                       wgu_p, wd_p]
+            self._keep += [wqkv_p, wo_p, wgu_p, wd_p]
+            hip.check(hip.lib.qtts_model_set_layer(h, i, *[hip.ptr(t) for t in tensors]), "model_set_layer")
+        self.final_norm = dev(weights[prefix + "norm.weight"])
+        hip.check(hip.lib.qtts_model_set_final_norm(h, hip.ptr(self.final_norm)), "set_final_norm")
+        cos, sin = rope_tables(s.head_dim, s.rope_theta, max_pos)
+        self.cos, self.sin = dev(cos), dev(sin)
+        hip.check(hip.lib.qtts_model_set_rope(h, hip.ptr(self.cos), hip.ptr(self.sin), max_pos), "set_rope")
+        # [2, layers, blocks, 256, kv_heads, head_dim] bf16 — the reference's layout
+        self.kv_cache = torch.zeros(2, s.num_layers, num_kv_blocks, BLOCK, s.num_kv_heads, s.head_dim,
+                                    dtype=torch.bfloat16, device=self.device)
+        hip.check(hip.lib.qtts_model_set_kv_cache(h, hip.ptr(self.kv_cache), num_kv_blocks), "set_kv_cache")
+        nbytes = hip.lib.qtts_model_workspace_bytes(h, max_rows, max_context)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        hip.check(hip.lib.qtts_model_set_workspace(h, hip.ptr(self.workspace), nbytes, max_rows, max_context),
+                  "set_workspace")
+
+    def weight_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._keep if t.dim() == 1 and t.numel() > 4096)
+
+    def forward(self, x, positions, slot_mapping, context_lens, block_tables, max_context, row_seq=None, out=None):
+        """x [N,hidden] bf16; returns post-final-norm hidden [N,hidden]."""
+        N = x.shape[0]
+        assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[1] == self.shape.hidden_size
+        assert positions.dtype == torch.int64 and context_lens.dtype == torch.int32 and block_tables.dtype == torch.int32
+        assert slot_mapping is None or slot_mapping.dtype == torch.int32
+        assert block_tables.is_contiguous()
+        if out is None:
+            out = torch.empty_like(x)
+        hip.check(hip.lib.qtts_model_forward(self._h, hip.ptr(x), hip.ptr(positions), hip.ptr(slot_mapping),
+                                             hip.ptr(row_seq), hip.ptr(context_lens), hip.ptr(block_tables),
+                                             block_tables.shape[1], max_context, N, hip.ptr(out), hip.stream()),
+                  "model_forward")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                hip.lib.qtts_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -1,0 +1,160 @@
+"""GPU parity at engine level: TalkerLLM / PredictorLLM (HIP path through the C ABI)
+against the fixtures the reference's modules produced and against the CPU oracle.
+
+Greedy token ids must be identical to the reference's.  Where the reference's own
+top-2 logit margin is below MARGIN_TOL (a tie or near-tie in bf16 logits) an id may
+legitimately flip with the fp32 summation order; the comparison then stops at that
+position, which the test reports.  Hidden states / logits: one bf16 ulp-level
+tolerance (atol 4e-2 on O(1) post-norm values after two layers)."""
+import numpy as np
+import pytest
+import torch
+
+import qtts_oracle as O
+from helpers import golden_weights, load_npz, oracle_cfgs
+from nano_qwen3tts_vllm.utils import synthetic
+
+pytestmark = pytest.mark.gpu
+MARGIN_TOL = 0.0625
+
+
+@pytest.fixture(scope="module", params=[("tiny", 11, "tiny"), ("tiny-id", 12, "tiny_id")])
+def setup(request, tmp_path_factory):
+    size, seed, tag = request.param
+    d = str(tmp_path_factory.mktemp(f"model_{tag}"))
+    import json, os
+    from safetensors.torch import save_file
+    cfg, sd, tw, pw = golden_weights(size, seed)
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+    save_file(sd, os.path.join(d, "model.safetensors"))
+    return d, cfg, tw, pw, load_npz(f"model_{tag}.npz")
+
+
+def greedy_sp(max_tokens):
+    from nano_qwen3tts_vllm.sampling_params import SamplingParams
+    return SamplingParams(temperature=1.0, max_tokens=max_tokens, do_sample=False)
+
+
+def close(got, want, atol=4e-2, rtol=4e-2):
+    got, want = got.float().cpu(), torch.as_tensor(want).float()
+    return torch.allclose(got, want, atol=atol, rtol=rtol), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("eager", [True, False])
+def test_talker_engine_matches_reference_fixture(setup, eager):
+    from nano_qwen3tts_vllm.llm import TalkerLLM
+    d, cfg, tw, pw, g = setup
+    llm = TalkerLLM(d, enforce_eager=eager, num_kvcache_blocks=8, max_num_seqs=16, max_num_batched_tokens=1024)
+    # reproduce the fixture's block tables: prompts of 5, 9, 260 tokens got blocks [3], [0], [5,1]
+    llm.scheduler.block_manager.free_block_ids = type(llm.scheduler.block_manager.free_block_ids)([3, 0, 5, 1, 2, 4, 6, 7])
+    prompts = [torch.from_numpy(g[f"t_prompt{i}"]).unsqueeze(0) for i in range(3)]
+    for i, p in enumerate(prompts):
+        llm.add_request([p], greedy_sp(1), request_id=f"r{i}")
+    _, n, outs = llm.step_with_outputs()
+    assert n == 5 + 9 + 260 + 3      # len(seq) after the appended token, summed (reference's accounting)
+    hid = torch.stack([o[3] for o in outs])
+    ok, md = close(hid, g["t_prefill_hidden"])
+    assert ok, f"prefill hidden max diff {md}"
+    want_tok = np.argmax(g["t_prefill_logits"], axis=-1)
+    top2 = np.sort(g["t_prefill_logits"], axis=-1)[:, -2:]
+    for i, o in enumerate(outs):
+        if top2[i, 1] - top2[i, 0] > MARGIN_TOL:
+            assert o[2][-1] == want_tok[i]
+    for step in range(3):
+        emb = torch.from_numpy(g[f"t_dec{step}_in"])
+        for i in range(3):
+            llm.add_request([emb[i].view(1, 1, -1)], greedy_sp(1), request_id=f"r{i}")
+        _, n, outs = llm.step_with_outputs()
+        assert n == -3
+        hid = torch.stack([o[3] for o in outs])
+        # NOTE the fixture's decode steps follow the fixture's prefill, and so do these (same KV content)
+        ok, md = close(hid, g[f"t_dec{step}_hidden"])
+        assert ok, f"decode {step} hidden max diff {md}"
+        lg = g[f"t_dec{step}_logits"]
+        top2 = np.sort(lg, axis=-1)[:, -2:]
+        for i, o in enumerate(outs):
+            if top2[i, 1] - top2[i, 0] > MARGIN_TOL:
+                assert o[2][-1] == int(np.argmax(lg[i]))
+    for i in range(3):
+        llm.clear_request(f"r{i}")
+    assert len(llm.scheduler.block_manager.free_block_ids) == 8
+    llm.exit()
+
+
+@pytest.mark.parametrize("burst", ["1", "0"])
+def test_predictor_engine_burst_matches_reference_fixture(setup, burst, monkeypatch):
+    from nano_qwen3tts_vllm.llm import PredictorLLM
+    monkeypatch.setenv("QTTS_PREDICTOR_BURST", burst)
+    d, cfg, tw, pw, g = setup
+    llm = PredictorLLM(d, enforce_eager=False, num_kvcache_blocks=4, max_num_seqs=16, max_num_batched_tokens=1024)
+    pin = torch.from_numpy(g["p_in"])
+    for i in range(3):
+        llm.add_request([pin[i].unsqueeze(0)], greedy_sp(17), request_id=f"p{i}")
+    done = {}
+    steps = 0
+    while llm.scheduler.waiting or llm.scheduler.running:
+        outs, _ = llm.step()
+        steps += 1
+        for rid, _sid, toks in outs:
+            done[rid] = toks
+    assert steps == (1 if burst == "1" else 15)
+    want = g["p_tokens"]
+    lg = g["p_logits"]                       # [3,15,V]
+    top2 = np.sort(lg, axis=-1)[..., -2:]
+    margin = top2[..., 1] - top2[..., 0]
+    for i in range(3):
+        got = done[f"p{i}"]
+        assert len(got) == 15
+        for t in range(15):
+            if margin[i, t] <= MARGIN_TOL:
+                break                        # near-tie in the reference's own logits: later ids may differ
+            assert got[t] == int(want[i, t]), f"seq {i} step {t}: {got[t]} != {want[i, t]} (margin {margin[i, t]})"
+    assert len(llm.scheduler.block_manager.free_block_ids) == 4
+    llm.exit()
+
+
+def test_frame_loop_ids_match_reference_fixture(setup):
+    """Talker -> predictor burst -> fp32 glue -> talker, 2 streams x 6 frames, greedy."""
+    from nano_qwen3tts_vllm.llm import PredictorLLM, TalkerLLM
+    d, cfg, tw, pw, g = setup
+    talker = TalkerLLM(d, num_kvcache_blocks=8, max_num_seqs=16, max_num_batched_tokens=1024)
+    pred = PredictorLLM(d, num_kvcache_blocks=8, max_num_seqs=16, max_num_batched_tokens=1024)
+    S, NF = 2, 6
+    prompts = [torch.from_numpy(g[f"f_prompt{i}"]).unsqueeze(0) for i in range(S)]
+    text_adds = torch.from_numpy(g["f_text_adds"])
+    emb_t = tw["model.codec_embedding.weight"].float()
+    emb_p = [pw[f"model.codec_embedding.{i}.weight"].float() for i in range(15)]
+    for i in range(S):
+        talker.add_request([prompts[i]], greedy_sp(1), request_id=f"s{i}")
+    frames = np.zeros((S, NF, 16), dtype=np.int64)
+    for f in range(NF):
+        _, _, outs = talker.step_with_outputs()
+        by_rid = {o[0]: o for o in outs}
+        for i in range(S):
+            o = by_rid[f"s{i}"]
+            tok0 = o[2][-1]
+            hidden = o[3].float().cpu()
+            pin = torch.stack([hidden, emb_t[tok0]], 0).unsqueeze(0)
+            pred.add_request([pin], greedy_sp(17), request_id=f"s{i}")
+        res = {}
+        while pred.scheduler.waiting or pred.scheduler.running:
+            po, _ = pred.step()
+            for rid, _sid, toks in po:
+                res[rid] = toks
+        for i in range(S):
+            tok0 = by_rid[f"s{i}"][2][-1]
+            frames[i, f, 0] = tok0
+            frames[i, f, 1:] = res[f"s{i}"]
+            nxt = O.frame_glue(tw, pw, tok0, res[f"s{i}"], text_adds[i, f])
+            talker.add_request([nxt.view(1, 1, -1)], greedy_sp(1), request_id=f"s{i}")
+    want, margins = g["f_frames"], g["f_margins"]
+    for i in range(S):
+        for f in range(NF):
+            if not np.array_equal(frames[i, f], want[i, f]):
+                # only acceptable behind a near-tie of the reference's own talker logits in this or an earlier frame
+                assert margins[i, :f + 1].min() <= MARGIN_TOL, (i, f, frames[i, f].tolist(), want[i, f].tolist())
+                break
+    # at least the first frame of every stream must agree outright
+    assert all(np.array_equal(frames[i, 0], want[i, 0]) or margins[i, 0] <= MARGIN_TOL for i in range(S))
+    talker.exit()
+    pred.exit()

@@ -1,0 +1,249 @@
+"""GPU parity: each HIP operator (called through the C ABI) against the CPU oracle.
+
+Tolerances.  Integer outputs (argmax, slot scatter) are exact.  bf16 outputs of
+fp32-accumulated reductions may differ from the oracle by the summation order:
+allowed difference is one bf16 ulp of the value (relative 2^-7) on at most 2 % of
+the elements; attention (fp32 softmax, parity unpinned upstream) atol 1e-2 / rtol 2e-2.
+"""
+import numpy as np
+import pytest
+import torch
+
+import qtts_oracle as O
+from helpers import bf, load_npz
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from nano_qwen3tts_vllm import hip as h
+    assert torch.cuda.is_available()
+    return h
+
+
+def assert_bf16_close(got, want, max_frac=0.02, what=""):
+    got = got.float().cpu()
+    want = want.float().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    diff = (got - want).abs()
+    ulp = want.abs().clamp_min(1e-30) * 2.0 ** -7 + 1e-6
+    bad = diff > ulp
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements beyond 1 bf16 ulp, max diff {float(diff.max())}"
+    frac = float((diff > 0).float().mean())
+    assert frac <= max_frac, f"{what}: {frac:.4f} of elements differ (allowed {max_frac})"
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 512, 256), (3, 256, 128), (8, 4096, 2048), (8, 2048, 6144), (16, 1024, 3072),
+                                   (17, 2048, 1024), (40, 512, 512), (8, 3072, 2048)])
+def test_linear_plain(hip, M, N, K):
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    want = torch.nn.functional.linear(x, w)
+    wp = hip.pack_weight(w.to(DEV))
+    got = hip.linear(x.to(DEV), wp, N)
+    torch.cuda.synchronize()
+    assert_bf16_close(got, want, what=f"linear {M}x{N}x{K}")
+
+
+def test_linear_bias_residual_norm(hip):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 6, 1024, 2048
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.03).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    r = torch.randn(M, N, generator=g).bfloat16()
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16()
+    wp = hip.pack_weight(w.to(DEV))
+    # bias (the predictor's small_to_mtp_projection, P/models/qwen3_tts_predictor.py:59)
+    assert_bf16_close(hip.linear(x.to(DEV), wp, N, bias=b.to(DEV)), torch.nn.functional.linear(x, w, b), what="bias")
+    # residual: `residual + linear(x)` (P/models/qwen3_tts_share.py:171)
+    assert_bf16_close(hip.linear(x.to(DEV), wp, N, residual=r.to(DEV)), r + torch.nn.functional.linear(x, w), what="residual")
+    # fused RMSNorm prologue
+    want = torch.nn.functional.linear(O.rms_norm(x, nw, 1e-6), w)
+    assert_bf16_close(hip.linear(x.to(DEV), wp, N, norm_w=nw.to(DEV), eps=1e-6), want, what="norm")
+
+
+@pytest.mark.parametrize("M,I,K", [(2, 256, 128), (8, 6144, 2048), (8, 3072, 1024), (20, 512, 256)])
+def test_linear_swiglu(hip, M, I, K):
+    g = torch.Generator().manual_seed(I + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    wg = (torch.randn(I, K, generator=g) * 0.05).bfloat16()
+    wu = (torch.randn(I, K, generator=g) * 0.05).bfloat16()
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16()
+    h = O.rms_norm(x, nw, 1e-6)
+    want = O.silu_mul(torch.nn.functional.linear(h, wg), torch.nn.functional.linear(h, wu))
+    wp = hip.pack_gate_up(wg.to(DEV), wu.to(DEV))
+    got = hip.linear_swiglu(x.to(DEV), wp, I, norm_w=nw.to(DEV), eps=1e-6)
+    # two chained roundings: a 1-ulp flip of gate or up moves the product by up to 2 ulp
+    got, want = got.float().cpu(), want.float()
+    diff = (got - want).abs()
+    assert float((diff > want.abs() * 2.0 ** -6 + 1e-6).float().mean()) == 0.0
+    assert float((diff > 0).float().mean()) < 0.03
+
+
+def test_linear_rejects_bad_shapes(hip):
+    x = torch.zeros(2, 100, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(16 * 128, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(hip.QttsError):
+        hip.linear(x, w, 16)          # K=100 is not a multiple of 32
+
+
+def test_rmsnorm_golden(hip):
+    g = load_npz("ops.npz")
+    got = hip.rmsnorm(bf(g["rms_x"]).to(DEV), bf(g["rms_w"]).to(DEV), 1e-6)
+    assert_bf16_close(got, bf(g["rms_y"]), max_frac=0.005, what="rmsnorm")
+
+
+def _rope_tables(theta, max_pos=2048):
+    from nano_qwen3tts_vllm.models.hip_decoder import rope_tables
+    c, s = rope_tables(128, theta, max_pos)
+    return c.to(DEV), s.to(DEV)
+
+
+def test_qknorm_rope_store_golden(hip):
+    """Fixture vectors produced by the reference's Qwen3TTSRMSNorm + TalkerRotaryEmbedding."""
+    g = load_npz("ops.npz")
+    pos = torch.from_numpy(g["rope_pos"])
+    q, k = bf(g["rope_q"]), bf(g["rope_k"])         # [6,4,128], [6,2,128]
+    N, Hq, Hkv = 6, 4, 2
+    v = torch.randn(N, Hkv, 128).bfloat16()
+    ones = torch.ones(128).bfloat16()
+    # norm weights 1 and pre-normalised inputs are not available in the fixture; use the oracle for
+    # the norm step (itself pinned by test_oracle_golden) and the fixture for RoPE-only parity below.
+    qw = (1 + 0.1 * torch.randn(128)).bfloat16()
+    kw = (1 + 0.1 * torch.randn(128)).bfloat16()
+    qn, kn = O.rms_norm(q, qw, 1e-6), O.rms_norm(k, kw, 1e-6)
+    cos, sin = O.rope_tables(pos, 128, 1000000.0)
+    qo, ko = O.apply_rope(qn, kn, cos, sin)
+    qkv = torch.cat([q.reshape(N, -1), k.reshape(N, -1), v.reshape(N, -1)], 1).contiguous().to(DEV)
+    kc = torch.zeros(4, 256, Hkv, 128, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    slots = torch.tensor([5, 256 + 7, -1, 3 * 256 + 255, 0, 600], dtype=torch.int32)
+    ct, st = _rope_tables(1000000.0)
+    hip.qknorm_rope_store(qkv, qw.to(DEV), kw.to(DEV), 1e-6, ct, st, pos.to(DEV), slots.to(DEV), kc, vc, Hq, Hkv)
+    torch.cuda.synchronize()
+    got = qkv.cpu()
+    assert_bf16_close(got[:, :Hq * 128].reshape(N, Hq, 128), qo, max_frac=0.01, what="q rope")
+    assert_bf16_close(got[:, Hq * 128:(Hq + Hkv) * 128].reshape(N, Hkv, 128), ko, max_frac=0.01, what="k rope")
+    kcf, vcf = kc.cpu().view(-1, Hkv, 128), vc.cpu().view(-1, Hkv, 128)
+    for i, s in enumerate(slots.tolist()):
+        if s < 0:
+            continue
+        assert torch.equal(kcf[s], got[i, Hq * 128:(Hq + Hkv) * 128].reshape(Hkv, 128))
+        assert torch.equal(vcf[s], v[i])
+    used = [s for s in slots.tolist() if s >= 0]
+    mask = torch.ones(kcf.shape[0], dtype=torch.bool)
+    mask[used] = False
+    assert float(kcf[mask].abs().sum()) == 0.0 and float(vcf[mask].abs().sum()) == 0.0   # slot -1 skipped, nothing else touched
+
+    # RoPE alone against the reference's own outputs: unit norm weights and inputs whose RMS is exactly 1
+    # are not constructible in bf16, so compare through the oracle path above and, separately, check the
+    # fixture's reference outputs with the oracle tables (bit-exact on CPU in test_oracle_golden).
+    qo_ref, ko_ref = O.apply_rope(q, k, cos, sin)
+    assert np.array_equal(qo_ref.float().numpy(), g["mrope_qo"]) and np.array_equal(ko_ref.float().numpy(), g["mrope_ko"])
+
+
+def test_store_kvcache(hip):
+    N, Hkv = 7, 8
+    k = torch.randn(N, Hkv, 128).bfloat16().to(DEV)
+    v = torch.randn(N, Hkv, 128).bfloat16().to(DEV)
+    kc = torch.zeros(3, 256, Hkv, 128, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    slots = torch.tensor([0, 1, -1, 300, 767, -1, 256], dtype=torch.int32, device=DEV)
+    hip.store_kvcache(k, v, kc, vc, slots)
+    kco = torch.zeros(3, 256, Hkv, 128, dtype=torch.bfloat16)
+    vco = torch.zeros_like(kco)
+    O.store_kvcache(k.cpu(), v.cpu(), kco, vco, slots.cpu())
+    assert torch.equal(kc.cpu(), kco) and torch.equal(vc.cpu(), vco)
+
+
+@pytest.mark.parametrize("Hq,Hkv,ctxs", [(16, 8, [1, 17, 128, 129, 300, 1024]), (4, 2, [3, 260, 0, 511]), (16, 8, [2, 3, 16])])
+def test_paged_attention_decode(hip, Hq, Hkv, ctxs):
+    g = torch.Generator().manual_seed(sum(ctxs))
+    B = len(ctxs)
+    nblk = 4 * B + 1
+    kc = torch.randn(nblk, 256, Hkv, 128, generator=g).bfloat16()
+    vc = torch.randn(nblk, 256, Hkv, 128, generator=g).bfloat16()
+    q = torch.randn(B, Hq, 128, generator=g).bfloat16()
+    perm = torch.randperm(nblk - 1, generator=g) + 1          # scattered block ids
+    bt = perm[:4 * B].reshape(B, 4).to(torch.int32)
+    cl = torch.tensor(ctxs, dtype=torch.int32)
+    want = O.attention_decode(q, kc, vc, bt, cl, 128 ** -0.5)
+    maxc = max(max(ctxs), 1)
+    got = hip.paged_attention(q.reshape(B, -1).to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV), cl.to(DEV), maxc,
+                              128 ** -0.5, Hq, Hkv)
+    torch.cuda.synchronize()
+    assert torch.allclose(got.float().cpu().view(B, Hq, 128), want.float(), atol=1e-2, rtol=2e-2)
+    for i, c in enumerate(ctxs):
+        if c == 0:
+            assert float(got[i].abs().sum()) == 0.0
+
+
+def test_paged_attention_prefill_rows(hip):
+    """Causal prefill expressed as per-token rows over the just-stored cache equals
+    the packed varlen formulation (P/layers/attention.py:88-91)."""
+    g = torch.Generator().manual_seed(3)
+    Hq, Hkv = 4, 2
+    lens = [5, 140]
+    N = sum(lens)
+    q = torch.randn(N, Hq, 128, generator=g).bfloat16()
+    k = torch.randn(N, Hkv, 128, generator=g).bfloat16()
+    v = torch.randn(N, Hkv, 128, generator=g).bfloat16()
+    cu = [0, 5, 145]
+    want = O.attention_prefill(q, k, v, cu, 128 ** -0.5)
+    kc = torch.zeros(3, 256, Hkv, 128, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    bt = torch.tensor([[2], [0]], dtype=torch.int32)
+    slots, row_seq, ctx = [], [], []
+    for s, L in enumerate(lens):
+        for t in range(L):
+            slots.append(int(bt[s, 0]) * 256 + t)
+            row_seq.append(s)
+            ctx.append(t + 1)
+    O.store_kvcache(k, v, kc, vc, torch.tensor(slots))
+    got = hip.paged_attention(q.reshape(N, -1).to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV),
+                              torch.tensor(ctx, dtype=torch.int32, device=DEV), max(lens), 128 ** -0.5, Hq, Hkv,
+                              row_seq=torch.tensor(row_seq, dtype=torch.int32, device=DEV))
+    assert torch.allclose(got.float().cpu().view(N, Hq, 128), want.float(), atol=1e-2, rtol=2e-2)
+
+
+def test_argmax_ties_lowest_index(hip):
+    lg = torch.randn(5, 3072).bfloat16()
+    lg[0, 100] = 50.0
+    lg[0, 2000] = 50.0            # exact tie -> index 100
+    lg[1, 3071] = 60.0
+    lg[2, 0] = 70.0
+    got = hip.argmax(lg.to(DEV)).cpu()
+    assert torch.equal(got, O.greedy(lg))
+    assert got[0] == 100 and got[1] == 3071 and got[2] == 0
+
+
+def test_sample_topk_distribution(hip):
+    """Draws stay inside the reference's top-k support and follow its probabilities
+    (P/layers/sampler.py:15-22).  The RNG stream differs from torch's: statistical check only."""
+    g = torch.Generator().manual_seed(9)
+    V, n = 2048, 4000
+    row = (torch.randn(V, generator=g) * 2).bfloat16()
+    logits = row.unsqueeze(0).repeat(n, 1).contiguous()
+    temps = torch.full((n,), 0.9)
+    probs = O.topk_probs(row.unsqueeze(0), temps[:1], 50)[0]
+    got = hip.sample_topk(logits.to(DEV), temps.to(DEV), 50, seed=123, offset=0).cpu()
+    support = set(torch.nonzero(probs > 0).flatten().tolist())
+    assert len(support) >= 50 and set(got.tolist()) <= support
+    freq = torch.bincount(got, minlength=V).float() / n
+    assert float((freq - probs).abs().max()) < 0.03
+    again = hip.sample_topk(logits.to(DEV), temps.to(DEV), 50, seed=123, offset=0).cpu()
+    assert torch.equal(again, got)                     # counter-based: reproducible
+    other = hip.sample_topk(logits.to(DEV), temps.to(DEV), 50, seed=123, offset=1).cpu()
+    assert not torch.equal(other, got)
+
+
+def test_embedding_gather(hip):
+    table = torch.randn(300, 256).bfloat16()
+    ids = torch.tensor([0, 299, 5, 5], dtype=torch.int64)
+    got = hip.embedding_gather(table.to(DEV), ids.to(DEV)).cpu()
+    assert torch.equal(got, table[ids])
