@@ -85,6 +85,28 @@ class ModelRunner:
         self.max_blocks_per_seq = (config.max_model_len + self.block_size - 1) // self.block_size
         self.rng_seed = int(os.environ.get("QTTS_SEED", "0"))
         self.rng_offset = 0
+        # All launches go to one side stream: hipGraph capture is not allowed on the legacy
+        # default stream, and a private stream keeps replays ordered with the staging copies.
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    def on_stream(self):
+        """Context manager: make `self.stream` current, ordered after the caller's stream on entry
+        and with the caller's stream ordered after it on exit."""
+        runner = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                self_inner.outer = torch.cuda.current_stream(runner.device)
+                runner.stream.wait_stream(self_inner.outer)
+                self_inner.cm = torch.cuda.stream(runner.stream)
+                self_inner.cm.__enter__()
+
+            def __exit__(self_inner, *exc):
+                self_inner.cm.__exit__(*exc)
+                self_inner.outer.wait_stream(runner.stream)
+                return False
+
+        return _Ctx()
 
     # ---- sizing -----------------------------------------------------------------
     def kv_blocks_for(self, block_bytes: int, reserve_bytes: int) -> int:

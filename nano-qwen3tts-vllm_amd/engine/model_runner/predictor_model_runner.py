@@ -122,6 +122,10 @@ class PredictorModelRunner(ModelRunner):
     # ---- one model step (reference contract) ------------------------------------------
     @torch.inference_mode()
     def run(self, seqs: list[PredictorSequence], is_prefill: bool) -> list[int]:
+        with self.on_stream():
+            return self._run(seqs, is_prefill)
+
+    def _run(self, seqs: list[PredictorSequence], is_prefill: bool) -> list[int]:
         S, mb, st = len(seqs), self.max_blocks_per_seq, self.pstage
         steps = [s.generation_steps for s in seqs]
         if is_prefill:
@@ -200,6 +204,10 @@ class PredictorModelRunner(ModelRunner):
     @torch.inference_mode()
     def run_burst(self, seqs: list[PredictorSequence]) -> list[list[int]]:
         """All `n_gen` tokens of freshly admitted sequences (each holding a [1,2,H] prompt)."""
+        with self.on_stream():
+            return self._run_burst(seqs)
+
+    def _run_burst(self, seqs: list[PredictorSequence]) -> list[list[int]]:
         S, mb, st = len(seqs), self.max_blocks_per_seq, self.bstage
         bs = next(b for b in self.burst_bs if b >= S)
         assert all(len(s) == 2 and s.generation_steps == 0 for s in seqs)

@@ -128,6 +128,10 @@ class TalkerModeModelRunner(ModelRunner):
 
     @torch.inference_mode()
     def run(self, seqs: list[Sequence], is_prefill: bool):
+        with self.on_stream():
+            return self._run(seqs, is_prefill)
+
+    def _run(self, seqs: list[Sequence], is_prefill: bool):
         S = len(seqs)
         if is_prefill:
             N, S, cu, max_len = self.prepare_prefill(seqs)

@@ -188,6 +188,8 @@ class Graph:
     @staticmethod
     def capture(fn):
         s = stream()
+        if s == 0:
+            raise QttsError("graph capture needs a non-default stream (use torch.cuda.stream(...))")
         check(lib.qtts_graph_begin(s), "graph_begin")
         try:
             fn()
