@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: codec tokens/s and RTF at 8 concurrent streams per GPU,
+Qwen3-TTS-12Hz-1.7B shapes (BASELINE.json configs[2]), synthetic weights and prompts.
+
+    python bench.py --gpus 1 --steps 100 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one 16-code frame for every stream of this rank's replica (talker decode +
+15-step predictor burst + frame glue, one hipGraph).  Ranks are independent replicas
+(no collective on the data path); the barrier only brackets the timed region.
+Prefill of the prompts happens before the timed region and is reported separately
+as first-frame latency.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+FRAME_SECONDS = 0.08          # 12.5 Hz codec frames
+HBM_PEAK = 8.0e12             # B/s, MI355X HBM3E (spec)
+
+
+def make_weights(cfg, device, seed=1234):
+    """N(0, 0.02^2) bf16 weights of the released 1.7B architecture, generated on the device."""
+    from nano_qwen3tts_vllm.utils import synthetic
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for k, shp in synthetic.checkpoint_shapes(cfg).items():
+        if k.endswith("norm.weight") or k.endswith("layernorm.weight"):
+            sd[k] = torch.ones(shp, dtype=torch.bfloat16, device=device)
+        else:
+            std = 0.05 if "codec_embedding" in k else 0.02
+            sd[k] = (torch.randn(shp, generator=g, device=device, dtype=torch.float32) * std).to(torch.bfloat16)
+    return synthetic.split_state_dict(sd)
+
+
+def algorithmic_bytes_per_frame(cfg, B, mean_ctx):
+    """Bytes one frame must move: every talker weight once, the predictor's per-step weights
+    15 times, plus the KV rows attention reads (bf16)."""
+    from nano_qwen3tts_vllm.utils import synthetic
+    shapes = synthetic.checkpoint_shapes(cfg)
+    numel = lambda k: int(torch.tensor(shapes[k]).prod())
+    t = cfg["talker_config"]
+    p = t["code_predictor_config"]
+    talker = sum(numel(k) for k in shapes if k.startswith("talker.model.layers.")) + numel("talker.model.norm.weight") \
+        + numel("talker.codec_head.weight")
+    pred_layers = sum(numel(k) for k in shapes if k.startswith("talker.code_predictor.model.layers.")) \
+        + numel("talker.code_predictor.model.norm.weight")
+    pred_step = pred_layers + numel("talker.code_predictor.lm_head.0.weight")
+    if "talker.code_predictor.small_to_mtp_projection.weight" in shapes:
+        pred_step += numel("talker.code_predictor.small_to_mtp_projection.weight")
+    kv_t = 2 * t["num_hidden_layers"] * t["num_key_value_heads"] * t["head_dim"] * 2
+    kv_p = 2 * p["num_hidden_layers"] * p["num_key_value_heads"] * p["head_dim"] * 2
+    n_gen = p["num_code_groups"] - 1
+    pred_ctx = sum(range(2, 2 + n_gen))          # 2..16 cached positions read over the burst
+    return 2 * talker + 2 * n_gen * pred_step + B * mean_ctx * kv_t + B * pred_ctx * kv_p
+
+
+def time_dominant_kernel(fe, B, rounds=20):
+    """Average device time of the largest kernel of the path — the fused RMSNorm + gate/up GEMM +
+    SwiGLU launch of a talker layer — measured with HIP events on the engine's own stream, cycling
+    through all layers' weights so they come from HBM (28 x 50 MB >> the 256 MiB Infinity Cache)."""
+    from nano_qwen3tts_vllm import hip
+    tr = fe.tr
+    H, I = tr.shape.hidden_size, tr.shape.intermediate_size
+    x = torch.randn(B, H, device=tr.device).to(torch.bfloat16)
+    out = torch.empty(B, I, dtype=torch.bfloat16, device=tr.device)
+    # packed gate/up tensors are the 2*I*H-element buffers the decoder keeps
+    packed = [t for t in tr.decoder._keep if t.dim() == 1 and t.numel() == 2 * I * H]
+    norm = tr.decoder.final_norm
+    assert len(packed) == tr.shape.num_layers
+    with fe.tr.on_stream():
+        for w in packed:
+            hip.linear_swiglu(x, w, I, norm_w=norm, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(rounds):
+            for w in packed:
+                hip.linear_swiglu(x, w, I, norm_w=norm, out=out)
+        e1.record()
+        e1.synchronize()
+    n = rounds * len(packed)
+    sec = e0.elapsed_time(e1) * 1e-3 / n
+    return sec, 2 * I * H * 2 + B * H * 2 + B * I * 2
+
+
+def cpu_baseline(cfg, tw, pw, B, frames, prompt_len):
+    """The CPU oracle (oracle/qtts_oracle.py, torch eager bf16) on a bounded sample of the same
+    workload, timed on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import qtts_oracle as O
+    from helpers import oracle_cfgs
+    tc, pc = oracle_cfgs(cfg)
+    twc = {k: v.cpu() for k, v in tw.items()}
+    pwc = {k: v.cpu() for k, v in pw.items()}
+    g = torch.Generator().manual_seed(7)
+    H = tc.hidden_size
+    prompts = [torch.randn(prompt_len, H, generator=g) * 0.5 for _ in range(B)]
+    text = torch.randn(B, frames, H, generator=g) * 0.1
+    t0 = time.perf_counter()
+    O.frame_loop(twc, tc, pwc, pc, prompts, text, frames, num_blocks=4 * B)
+    dt = time.perf_counter() - t0
+    return dict(value=B * frames * 16 / dt, unit="codec tokens/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle frame loop (torch eager bf16 CPU): {B} streams, prompt {prompt_len} tokens (prefill included), "
+                       f"{frames} frames, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=8)
+    ap.add_argument("--size", default="1.7B")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    from nano_qwen3tts_vllm.sampling_params import SamplingParams
+    from nano_qwen3tts_vllm.utils import synthetic
+
+    cfg = synthetic.make_config(args.size)
+    tw, pw = make_weights(cfg, device)
+    mdir = tempfile.mkdtemp(prefix="qtts_bench_")
+    json.dump(cfg, open(os.path.join(mdir, "config.json"), "w"))
+    B = args.streams
+    n_frames = args.steps + args.warmup + 1
+    H = cfg["talker_config"]["hidden_size"]
+    fe = FrameEngine(mdir, max_streams=B, max_text_frames=n_frames + 1, talker_weights=tw, predictor_weights=pw,
+                     num_kvcache_blocks=4 * B, max_num_batched_tokens=4096, codec_eos=None)
+    greedy_t = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
+    greedy_p = SamplingParams(temperature=0.9, max_tokens=17, do_sample=False)
+    lens = [16, 48, 128, 200]
+    g = torch.Generator().manual_seed(1000 + rank)
+    first_frame_ms = []
+    prompt_lens = []
+    for i in range(B):
+        L = lens[i % len(lens)]
+        prompt_lens.append(L)
+        prompt = (torch.randn(L, H, generator=g) * 0.5).to(device)
+        text = (torch.randn(n_frames + 1, H, generator=g) * 0.1).to(device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fe.add_stream(prompt, text, max_frames=n_frames + 2, talker_sampling=greedy_t, predictor_sampling=greedy_p)
+        torch.cuda.synchronize()
+        first_frame_ms.append((time.perf_counter() - t0) * 1e3)      # prefill -> first talker id + hidden
+    # one frame with everything admitted: the rest of a stream's first 16-code frame
+    t0 = time.perf_counter()
+    fe.run_frames(1)
+    frame0_ms = (time.perf_counter() - t0) * 1e3
+
+    fe.run_frames(args.warmup)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    fe.run_frames(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        tokens = 16 * B * args.steps * world
+        value = tokens / elapsed
+        mean_ctx = sum(prompt_lens) / B + 1 + args.warmup + 1 + args.steps / 2
+        bytes_frame = algorithmic_bytes_per_frame(cfg, B, mean_ctx)
+        ksec, kbytes = time_dominant_kernel(fe, B)
+        out = {
+            "metric": "codec tokens/sec at 8 concurrent streams per GPU (RTF alongside), Qwen3-TTS-1.7B",
+            "value": value, "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Qwen3-TTS-12Hz-{args.size} shapes, {B} concurrent streams per GPU, greedy, "
+                                   f"continuous decode with one hipGraph per frame; prompts {prompt_lens} tokens, "
+                                   f"random-init weights", "streams_per_gpu": B, "replicas": world},
+            "rtf": ms_per_step * 1e-3 / FRAME_SECONDS,
+            "first_chunk_ms_p50": statistics.median(first_frame_ms) + frame0_ms,
+            "prefill_ms": first_frame_ms,
+            "frame_roofline": {"bound": "hbm", "bytes_per_frame": bytes_frame,
+                               "achieved": bytes_frame / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                               "unit": "GB/s", "frac": bytes_frame / (ms_per_step * 1e-3) / HBM_PEAK},
+            "roofline": {"bound": "hbm", "kernel": "linear_kernel<8,2,SILU,NORM> (talker RMSNorm+gate/up GEMM+SwiGLU)",
+                         "achieved": kbytes / ksec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": kbytes / ksec / HBM_PEAK, "traffic": None, "bytes_per_launch": kbytes,
+                         "us_per_launch": ksec * 1e6},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, tw, pw, B, args.cpu_frames, 16)
+        print(json.dumps(out), flush=True)
+    fe.exit()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

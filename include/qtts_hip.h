@@ -127,14 +127,28 @@ int qtts_embedding_gather(const void *table, const int64_t *ids, void *out, int 
                           int M, int H, int vocab, qtts_stream_t stream);
 
 /* Per-frame glue kept on the device (P/interface.py:1242-1252,1276-1285):
- * pred_in[b] = [hidden[b]; talker_emb[token0[b]]]                     ([B,2,H])
- * next[b]    = bf16( sum_{c<16} emb_c[codes[b,c]] (fp32) + text_add[b] (fp32) ) */
+ * pred_in[b] = [hidden[b]; talker_emb[token0[b]]]                              ([B,2,H])
+ * next[b]    = bf16( sum_{c<16} emb_c[code_c(b)] (fp32, c ascending) + text_add_b (fp32) )
+ * where code_0 = token0[b], code_c = pred_tokens[(c-1)*ldp + b], and text_add_b is
+ * the fp32 row text_add + b*ld_text + frame_idx[b]*H (frame_idx NULL: row 0) — the
+ * trailing text hidden or tts pad embedding the API adds each frame.  The 16 ids
+ * are also written to codes[b*16 + c] when codes != NULL. */
 int qtts_predictor_input(const void *hidden, const void *talker_emb, const int64_t *token0,
                          void *pred_in, int B, int H, int vocab, qtts_stream_t stream);
 int qtts_frame_glue(const void *talker_emb, const void *const *pred_emb_tables /* device array of 15 */,
-                    const int64_t *codes /* [B,16] */, const float *text_add /* [B,H] */,
-                    void *next /* [B,H] bf16 */, int B, int H, int talker_vocab, int pred_vocab,
-                    qtts_stream_t stream);
+                    const int64_t *token0, const int64_t *pred_tokens, int ldp,
+                    const float *text_add, long ld_text, const int32_t *frame_idx,
+                    void *next /* [B,H] bf16 */, int64_t *codes /* [B,16] or NULL */,
+                    int B, int H, int talker_vocab, int pred_vocab, qtts_stream_t stream);
+
+/* Device-side equivalent of re-running prepare_decode_talker for the next token
+ * (P/engine/model_runner/talker_mode_runner.py:116-140) for every active row
+ * (context_lens > 0): position+1, context+1, slot from the row's block table,
+ * frame_idx+1; *rng_counter += 64 (nullable).  No counterpart in the reference (it
+ * rebuilds the lists on the host). */
+int qtts_advance_decode(int64_t *positions, int32_t *slot_mapping, int32_t *context_lens,
+                        const int32_t *block_tables, int max_blocks, int32_t *frame_idx,
+                        uint64_t *rng_counter, int max_context, int B, qtts_stream_t stream);
 
 /* ---------------------------------------------------------------- decoder stack
  * One handle per model (talker or code predictor): the layer loop of

@@ -832,32 +832,73 @@ extern "C" int qtts_predictor_input(const void *hidden, const void *talker_emb, 
 }
 
 // Sum order follows torch's CPU reduction over the 16 stacked rows (sequential, row 0 first).
+// token0[b] is the talker's id, pred_tokens[c*ldp + b] the predictor's id for codebook c+1.
 __global__ __launch_bounds__(256) void frame_glue_kernel(const bf16_t *__restrict__ temb,
                                                          const bf16_t *const *__restrict__ ptabs,
-                                                         const int64_t *__restrict__ codes,
-                                                         const float *__restrict__ text_add,
-                                                         bf16_t *__restrict__ next, int H, int tv, int pv) {
+                                                         const int64_t *__restrict__ token0,
+                                                         const int64_t *__restrict__ pred_tokens, int ldp,
+                                                         const float *__restrict__ text_add, long ld_text,
+                                                         const int32_t *__restrict__ frame_idx,
+                                                         bf16_t *__restrict__ next, int64_t *__restrict__ codes,
+                                                         int H, int tv, int pv) {
     const int b = blockIdx.x;
+    __shared__ long ids[16];
+    if (threadIdx.x < 16) {
+        long id = threadIdx.x == 0 ? token0[b] : pred_tokens[(size_t)(threadIdx.x - 1) * ldp + b];
+        if (codes) codes[b * 16 + threadIdx.x] = id;
+        const int lim = threadIdx.x == 0 ? tv : pv;
+        ids[threadIdx.x] = id < 0 ? 0 : (id >= lim ? lim - 1 : id);
+    }
+    __syncthreads();
+    const float *ta = text_add + (size_t)b * ld_text + (frame_idx ? (size_t)frame_idx[b] * H : 0);
     for (int d = threadIdx.x; d < H; d += 256) {
-        long c0 = codes[b * 16];
-        c0 = c0 < 0 ? 0 : (c0 >= tv ? tv - 1 : c0);
-        float s = bf2f(temb[(size_t)c0 * H + d]);
-        for (int c = 1; c < 16; ++c) {
-            long id = codes[b * 16 + c];
-            id = id < 0 ? 0 : (id >= pv ? pv - 1 : id);
-            s += bf2f(ptabs[c - 1][(size_t)id * H + d]);
-        }
-        next[(size_t)b * H + d] = f2bf(s + text_add[(size_t)b * H + d]);
+        float s = bf2f(temb[(size_t)ids[0] * H + d]);
+#pragma unroll
+        for (int c = 1; c < 16; ++c) s += bf2f(ptabs[c - 1][(size_t)ids[c] * H + d]);
+        next[(size_t)b * H + d] = f2bf(s + ta[d]);
     }
 }
 
-extern "C" int qtts_frame_glue(const void *talker_emb, const void *const *pred_emb_tables, const int64_t *codes,
-                               const float *text_add, void *next, int B, int H, int talker_vocab, int pred_vocab,
-                               qtts_stream_t stream) {
-    QCHECK(talker_emb && pred_emb_tables && codes && text_add && next && B > 0 && H > 0, "frame_glue: bad arguments");
+extern "C" int qtts_frame_glue(const void *talker_emb, const void *const *pred_emb_tables, const int64_t *token0,
+                               const int64_t *pred_tokens, int ldp, const float *text_add, long ld_text,
+                               const int32_t *frame_idx, void *next, int64_t *codes, int B, int H, int talker_vocab,
+                               int pred_vocab, qtts_stream_t stream) {
+    QCHECK(talker_emb && pred_emb_tables && token0 && pred_tokens && text_add && next && B > 0 && H > 0 && ldp >= B,
+           "frame_glue: bad arguments");
     hipLaunchKernelGGL(frame_glue_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)talker_emb,
-                       (const bf16_t *const *)pred_emb_tables, codes, text_add, (bf16_t *)next, H, talker_vocab,
-                       pred_vocab);
+                       (const bf16_t *const *)pred_emb_tables, token0, pred_tokens, ldp, text_add, ld_text, frame_idx,
+                       (bf16_t *)next, codes, H, talker_vocab, pred_vocab);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+// Advances the per-stream decode metadata by one token on the device, so that a captured
+// frame graph can be replayed without a host upload: for active rows (context_lens > 0)
+// position += 1, context += 1, slot = table[(context-1) / 256] * 256 + (context-1) % 256,
+// frame_idx += 1.  Rows that would exceed max_context are frozen (context stays put).
+__global__ void advance_decode_kernel(int64_t *__restrict__ positions, int32_t *__restrict__ slots,
+                                      int32_t *__restrict__ ctx, const int32_t *__restrict__ tables, int max_blocks,
+                                      int32_t *__restrict__ frame_idx, uint64_t *__restrict__ rng_counter,
+                                      int max_context, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 && rng_counter) *rng_counter += 64;      // 64 distinct RNG offsets per frame
+    if (b >= B) return;
+    const int c = ctx[b];
+    if (c <= 0 || c >= max_context) return;
+    const int n = c + 1;
+    ctx[b] = n;
+    positions[b] += 1;
+    slots[b] = tables[(size_t)b * max_blocks + ((n - 1) >> 8)] * QTTS_KV_BLOCK + ((n - 1) & 255);
+    if (frame_idx) frame_idx[b] += 1;
+}
+
+extern "C" int qtts_advance_decode(int64_t *positions, int32_t *slot_mapping, int32_t *context_lens,
+                                   const int32_t *block_tables, int max_blocks, int32_t *frame_idx,
+                                   uint64_t *rng_counter, int max_context, int B, qtts_stream_t stream) {
+    QCHECK(positions && slot_mapping && context_lens && block_tables && B > 0 && max_blocks > 0 &&
+               max_context <= max_blocks * QTTS_KV_BLOCK, "advance_decode: bad arguments");
+    hipLaunchKernelGGL(advance_decode_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, positions,
+                       slot_mapping, context_lens, block_tables, max_blocks, frame_idx, rng_counter, max_context, B);
     QLAUNCH();
     return QTTS_OK;
 }

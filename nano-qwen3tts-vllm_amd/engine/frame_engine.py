@@ -1,0 +1,262 @@
+"""In-process frame loop with everything between two frames kept on the device.
+
+The reference glues talker and predictor per frame in the API process
+(P/interface.py:1241-1290; the in-process form survives as dead code at :1322-1366):
+hidden state and ids travel GPU -> host -> pickle -> host -> GPU twice per frame and
+the next talker input is summed on the host.  Here one captured hipGraph per frame does
+
+    predictor input  = [hidden ; codec_embedding(token0)]
+    15-step predictor burst (pick + token feedback on the device)
+    next talker input = sum of the 16 codebook embeddings + text/pad hidden   (fp32 -> bf16)
+    advance positions / slots / context lengths
+    talker decode step + codec head + pick                                   (-> hidden, token0 of the next frame)
+
+and the host only reads back the 16 ids per stream.  Streams occupy fixed rows;
+KV blocks for a stream's whole lifetime are reserved at admission (a stream needs
+at most 4 blocks), which also removes the reference's preemption path that cannot
+work for embedding-fed sequences.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from .. import hip
+from ..llm import PredictorLLM, TalkerLLM
+from ..sampling_params import SamplingParams
+from .sequence import Sequence
+
+CODEC_EOS = 2150        # hard-coded in the reference's API loop (P/interface.py:1233)
+
+
+class Stream:
+    def __init__(self, sid, row, seq, n_text):
+        self.sid, self.row, self.seq, self.n_text = sid, row, seq, n_text
+        self.frames: list[list[int]] = []
+        self.finished = False
+
+
+class FrameEngine:
+    def __init__(self, model_dir: str, max_streams: int = 8, max_text_frames: int = 1024, talker_weights=None,
+                 predictor_weights=None, enforce_eager: bool = False, codec_eos: int | None = CODEC_EOS, **kw):
+        kw = dict(kw)
+        kw.setdefault("max_num_seqs", max(max_streams, 1))
+        tkw = dict(kw, enforce_eager=enforce_eager)
+        if talker_weights is not None:
+            tkw["weights"] = talker_weights
+        pkw = dict(kw, enforce_eager=enforce_eager, num_kvcache_blocks=max_streams)
+        if predictor_weights is not None:
+            pkw["weights"] = predictor_weights
+        self.talker = TalkerLLM(model_dir, **tkw)
+        self.pred = PredictorLLM(model_dir, **pkw)
+        self.tr, self.pr = self.talker.model_runner, self.pred.model_runner
+        self.device = self.tr.device
+        self.max_streams = max_streams
+        self.enforce_eager = enforce_eager
+        self.codec_eos = codec_eos
+        H = self.tr.shape.hidden_size
+        self.H = H
+        self.max_text_frames = max_text_frames
+        dev = self.device
+        self.cur_hidden = torch.zeros(max_streams, H, dtype=torch.bfloat16, device=dev)
+        self.cur_token = torch.zeros(max_streams, dtype=torch.int64, device=dev)
+        self.next_x = torch.zeros(max_streams, H, dtype=torch.bfloat16, device=dev)
+        self.codes = torch.zeros(max_streams, 16, dtype=torch.int64, device=dev)
+        self.text_add = torch.zeros(max_streams, max_text_frames, H, dtype=torch.float32, device=dev)
+        self.frame_idx = torch.zeros(max_streams, dtype=torch.int32, device=dev)
+        self.rng = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.temps_t = torch.ones(max_streams, dtype=torch.float32, device=dev)
+        self.temps_p = torch.ones(max_streams, dtype=torch.float32, device=dev)
+        self.greedy = torch.ones(max_streams, dtype=torch.uint8, device=dev)
+        self.ptab_ptrs = torch.tensor([t.data_ptr() for t in self.pr.tables], dtype=torch.int64, device=dev)
+        self.rows: list[Stream | None] = [None] * max_streams
+        self.streams: dict[str, Stream] = {}
+        self.graphs: dict[tuple, hip.Graph] = {}
+        self._pred_meta_bs = None
+        self._next_sid = 0
+        self.stream = self.tr.stream
+        self.top_k = 50
+        # Run every kernel of the frame once, eagerly, with all rows inactive (context 0, slot -1:
+        # nothing is stored, nothing advances) so that no code object is first loaded under capture.
+        with self.tr.on_stream():
+            self._setup_predictor_meta(1)
+            self._frame_body(1, 128)
+            self._frame_body(1, 256)
+            self.rng.zero_()
+            self.tr.stream.synchronize()
+
+    # ---------------------------------------------------------------- admission
+    def add_stream(self, prompt_embeds: torch.Tensor, text_adds: torch.Tensor, max_frames: int,
+                   talker_sampling: SamplingParams | None = None, predictor_sampling: SamplingParams | None = None,
+                   sid: str | None = None) -> str:
+        """prompt_embeds [L,H]; text_adds fp32 [F,H]: what the API adds to the codec-embedding sum at
+        frame f (trailing text hiddens, then the tts pad embedding; the last row repeats)."""
+        row = next(i for i, s in enumerate(self.rows) if s is None)
+        sid = sid or f"stream-{self._next_sid}"
+        self._next_sid += 1
+        tsp = talker_sampling or SamplingParams(temperature=1.0, max_tokens=1)
+        psp = predictor_sampling or SamplingParams(temperature=0.9, max_tokens=17)
+        L = prompt_embeds.shape[-2]
+        total = L + max_frames + 1
+        assert total <= self.tr.config.max_model_len, "prompt + frames exceed max_model_len (1024)"
+        seq = Sequence([], input_embeds=prompt_embeds.reshape(1, L, -1), sampling_params=tsp, request_id=sid)
+        bm = self.talker.scheduler.block_manager
+        need = (total + 255) // 256
+        assert len(bm.free_block_ids) >= need, "out of KV blocks"
+        seq.block_table = [bm._take() for _ in range(need)]
+        with self.tr.on_stream():
+            toks, hidden = self.tr._run([seq], True)          # prefill (eager path of the runner)
+            seq.append_token(toks[0], None)
+            F = min(text_adds.shape[0], self.max_text_frames)
+            self.text_add[row, :F].copy_(text_adds[:F].to(self.device, torch.float32), non_blocking=True)
+            if F < self.max_text_frames:
+                self.text_add[row, F:] = text_adds[F - 1].to(self.device, torch.float32)
+            self.cur_hidden[row].copy_(hidden[0])
+            self.cur_token[row] = toks[0]
+            self.frame_idx[row] = 0
+            self.temps_t[row] = tsp.temperature
+            self.temps_p[row] = psp.temperature
+            self.greedy[row] = 0 if (tsp.do_sample or psp.do_sample) else 1
+            # talker decode metadata for the token that WILL be fed next: prepare_decode_talker semantics
+            st, mb = self.tr.dstage, self.tr.max_blocks_per_seq
+            n = len(seq)                                   # L + 1
+            st.h("positions")[row] = n - 1                 # advance_decode adds 1 before the first decode
+            st.h("ctx")[row] = n - 1
+            st.h("slots")[row] = -1
+            tab = st.h("tables")[:self.max_streams * mb].view(self.max_streams, mb)
+            tab[row].fill_(0)
+            tab[row, :need] = torch.tensor(seq.block_table, dtype=torch.int32)
+            self._sync_row_to_device(row)
+        s = Stream(sid, row, seq, F)
+        s.first_token = toks[0]
+        self.rows[row] = s
+        self.streams[sid] = s
+        return sid
+
+    def _sync_row_to_device(self, row):
+        st, mb = self.tr.dstage, self.tr.max_blocks_per_seq
+        for name in ("positions", "ctx", "slots"):
+            st.d(name)[row:row + 1].copy_(st.h(name)[row:row + 1], non_blocking=True)
+        st.d("tables")[row * mb:(row + 1) * mb].copy_(st.h("tables")[row * mb:(row + 1) * mb], non_blocking=True)
+
+    def remove_stream(self, sid: str):
+        s = self.streams.pop(sid, None)
+        if s is None:
+            return
+        self.rows[s.row] = None
+        st = self.tr.dstage
+        with self.tr.on_stream():
+            st.h("ctx")[s.row] = 0
+            st.h("slots")[s.row] = -1
+            self._sync_row_to_device(s.row)
+        self.talker.scheduler.block_manager.deallocate(s.seq)
+
+    # ---------------------------------------------------------------- the frame
+    def _bucket(self):
+        hi = max((i for i, s in enumerate(self.rows) if s is not None), default=-1) + 1
+        return next(b for b in self.tr.graph_bs if b >= max(hi, 1))
+
+    def _setup_predictor_meta(self, bs):
+        """Row r of the predictor batch always uses predictor KV block r, so the burst's metadata is
+        a constant of the bucket size."""
+        if self._pred_meta_bs == bs:
+            return
+        pr, st = self.pr, self.pr.bstage
+        n_gen, B = pr.n_gen, 256
+        n0 = 2 * bs
+        pos, slot, ctx, rs = st.h("positions"), st.h("slots"), st.h("ctx"), st.h("row_seq")
+        for i in range(bs):
+            rs[2 * i] = rs[2 * i + 1] = i
+            pos[2 * i], pos[2 * i + 1] = 0, 1
+            slot[2 * i], slot[2 * i + 1] = i * B, i * B + 1
+            ctx[2 * i], ctx[2 * i + 1] = 1, 2
+            for step in range(1, n_gen):
+                r = n0 + (step - 1) * bs + i
+                pos[r], slot[r], ctx[r] = step + 1, i * B + step + 1, step + 2
+        mb = pr.max_blocks_per_seq
+        tab = st.h("tables")[:bs * mb].view(bs, mb)
+        tab.fill_(0)
+        tab[:, 0] = torch.arange(bs, dtype=torch.int32)
+        st.upload()
+        self._pred_meta_bs = bs
+
+    def _frame_body(self, bs: int, max_context: int):
+        tr, pr, lib, s = self.tr, self.pr, hip.lib, hip.stream
+        H = self.H
+        hip.check(lib.qtts_predictor_input(hip.ptr(self.cur_hidden), hip.ptr(tr.codec_embedding), hip.ptr(self.cur_token),
+                                           hip.ptr(pr.e_buf), bs, H, tr.vocab, s()), "predictor_input")
+        pr._greedy_bytes, pr._top_k = self.greedy, self.top_k
+        pr._burst_temps, pr._burst_rng = self.temps_p, self.rng
+        pr._burst_body(bs)
+        hip.check(lib.qtts_frame_glue(hip.ptr(tr.codec_embedding), hip.ptr(self.ptab_ptrs), hip.ptr(self.cur_token),
+                                      hip.ptr(pr.burst_tokens), bs, hip.ptr(self.text_add),
+                                      self.max_text_frames * H, hip.ptr(self.frame_idx), hip.ptr(self.next_x),
+                                      hip.ptr(self.codes), bs, H, tr.vocab, pr.vocab, s()), "frame_glue")
+        st, mb = tr.dstage, tr.max_blocks_per_seq
+        hip.check(lib.qtts_advance_decode(hip.ptr(st.d("positions")), hip.ptr(st.d("slots")), hip.ptr(st.d("ctx")),
+                                          hip.ptr(st.d("tables")), mb, hip.ptr(self.frame_idx), hip.ptr(self.rng),
+                                          tr.config.max_model_len, bs, s()), "advance_decode")
+        tr.decoder.forward(self.next_x[:bs], st.d("positions")[:bs], st.d("slots")[:bs], st.d("ctx")[:bs],
+                           st.d("tables")[:bs * mb].view(bs, mb), max_context, out=self.cur_hidden[:bs])
+        hip.linear(self.cur_hidden[:bs], tr.codec_head, tr.vocab, out=tr.logits[:bs])
+        hip.check(lib.qtts_pick_token(hip.ptr(tr.logits), tr.vocab, hip.ptr(self.temps_t), hip.ptr(self.greedy),
+                                      self.top_k, tr.rng_seed, 32, hip.ptr(self.rng), hip.ptr(self.cur_token), 1, bs,
+                                      tr.vocab, s()), "pick_token")
+
+    def _max_ctx_bucket(self, extra_frames: int = 1) -> int:
+        mx = max((len(s.seq) + len(s.frames) + extra_frames for s in self.rows if s is not None), default=1)
+        mx = min(mx + 1, self.tr.config.max_model_len)
+        return min(((mx + 127) // 128) * 128, self.tr.config.max_model_len)
+
+    def _launch_frame(self, bs, max_ctx):
+        if self.enforce_eager:
+            self._frame_body(bs, max_ctx)
+            return
+        key = (bs, max_ctx)
+        g = self.graphs.get(key)
+        if g is None:
+            g = self.graphs[key] = hip.Graph.capture(lambda: self._frame_body(bs, max_ctx))
+        g.launch()
+
+    def run_frames(self, n: int) -> torch.Tensor:
+        """Generate n frames for every active stream back to back (no EOS handling: the caller asked
+        for exactly n).  Returns ids [n, bucket, 16] on the host; one synchronisation at the end."""
+        bs = self._bucket()
+        out = torch.empty(n, bs, 16, dtype=torch.int64).pin_memory()
+        with self.tr.on_stream():
+            self._setup_predictor_meta(bs)
+            for f in range(n):
+                self._launch_frame(bs, self._max_ctx_bucket(extra_frames=f + 1))
+                out[f].copy_(self.codes[:bs], non_blocking=True)
+            self.tr.stream.synchronize()
+        for s in self.rows:
+            if s is not None:
+                s.frames.extend(out[:, s.row].tolist())
+        return out
+
+    def step(self) -> dict[str, list[int]]:
+        """One frame for every active stream; streams whose talker id is the codec EOS finish
+        without yielding that frame (as P/interface.py:1233-1239)."""
+        if not self.streams:
+            return {}
+        bs = self._bucket()
+        with self.tr.on_stream():
+            self._setup_predictor_meta(bs)
+            self._launch_frame(bs, self._max_ctx_bucket())
+            codes = self.codes[:bs].tolist()
+        res = {}
+        for s in list(self.streams.values()):
+            c = codes[s.row]
+            if self.codec_eos is not None and c[0] == self.codec_eos:
+                s.finished = True
+                self.remove_stream(s.sid)
+                continue
+            s.frames.append(c)
+            res[s.sid] = c
+        return res
+
+    def exit(self):
+        self.graphs.clear()
+        self.talker.exit()
+        self.pred.exit()

@@ -174,9 +174,9 @@ class PredictorModelRunner(ModelRunner):
         stream = hip.stream
 
         def pick(step):
-            hip.check(hip.lib.qtts_pick_token(hip.ptr(self.logits), self.vocab, hip.ptr(st.d("temps")),
+            hip.check(hip.lib.qtts_pick_token(hip.ptr(self.logits), self.vocab, hip.ptr(self._burst_temps),
                                               hip.ptr(self._greedy_bytes), self._top_k, self.rng_seed, step,
-                                              hip.ptr(st.d("rng")), hip.ptr(self.burst_tokens) + 8 * step * bs, 1,
+                                              hip.ptr(self._burst_rng), hip.ptr(self.burst_tokens) + 8 * step * bs, 1,
                                               bs, self.vocab, stream()), "pick_token")
 
         # prefill: 2*bs rows
@@ -239,6 +239,7 @@ class PredictorModelRunner(ModelRunner):
         st.upload()
         self._greedy_bytes = self._greedy_u8(bs)
         self._top_k = seqs[0].top_k
+        self._burst_temps, self._burst_rng = st.d("temps"), st.d("rng")
         rows = [s.input_embeds.reshape(-1, s.input_embeds.shape[-1]) for s in seqs]
         self.e_buf[:2 * S].copy_(torch.cat(rows, 0).to(torch.bfloat16), non_blocking=True)
         if self.enforce_eager:

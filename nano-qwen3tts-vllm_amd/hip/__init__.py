@@ -41,7 +41,8 @@ _SIGS = {
     "qtts_pick_token": (_i, [_p, _i, _p, _p, _i, _u64, _u64, _p, _p, _i, _i, _i, _p]),
     "qtts_embedding_gather": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "qtts_predictor_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
-    "qtts_frame_glue": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "qtts_frame_glue": (_i, [_p, _p, _p, _p, _i, _p, C.c_long, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "qtts_advance_decode": (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _i, _p]),
     "qtts_model_create": (_p, [_i, _i, _i, _i, _i, _i, _f]),
     "qtts_model_destroy": (None, [_p]),
     "qtts_model_set_layer": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),

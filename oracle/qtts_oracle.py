@@ -381,19 +381,24 @@ def frame_loop(tw, tcfg, pw, pcfg, prompts, text_adds, n_frames, num_blocks=32):
     in one batch (the dead in-process loop P/interface.py:1322-1366 is the shape).
     prompts: list of [L,H] tensors; text_adds: fp32 [S, n_frames, H] (what the API
     process adds per step: trailing text hidden or the tts pad embedding).
-    Returns frames [S, n_frames, 16] (int64) and top-2 talker logit margins."""
+    Returns frames [S, n_frames, 16] (int64), the top-2 margin of the talker logits per frame, and
+    the smallest top-2 margin over all 16 picks of the frame (a pick whose margin is a bf16 ulp or
+    less may flip under a different fp32 summation order)."""
     talker = OracleTalker(tw, tcfg, num_blocks)
     pred = OraclePredictor(pw, pcfg, num_blocks)
     S = len(prompts)
     frames = torch.zeros(S, n_frames, 16, dtype=torch.int64)
     margins = torch.zeros(S, n_frames)
+    pick_margins = torch.zeros(S, n_frames)
     seqs, tok, hid, logits = talker.prefill(prompts)
     for f in range(n_frames):
         top2 = torch.topk(logits.float(), 2, dim=-1)[0]
         margins[:, f] = top2[:, 0] - top2[:, 1]
         emb0 = tw["model.codec_embedding.weight"][torch.tensor(tok)].float()
         pin = [torch.stack([hid[i].float(), emb0[i]], 0) for i in range(S)]
-        ptoks = pred.burst(pin)
+        ptoks, plogits = pred.burst(pin, return_logits=True)
+        pm = torch.stack([(lambda t2: t2[:, 0] - t2[:, 1])(torch.topk(l.float(), 2, dim=-1)[0]) for l in plogits], 1)
+        pick_margins[:, f] = torch.minimum(margins[:, f], pm.min(dim=1)[0])
         nxt = []
         for i in range(S):
             frames[i, f, 0] = tok[i]
@@ -401,4 +406,4 @@ def frame_loop(tw, tcfg, pw, pcfg, prompts, text_adds, n_frames, num_blocks=32):
             nxt.append(frame_glue(tw, pw, tok[i], ptoks[i], text_adds[i, f]))
         if f + 1 < n_frames:
             tok, hid, logits = talker.decode(seqs, torch.stack(nxt, 0))
-    return frames, margins
+    return frames, margins, pick_margins

@@ -1,0 +1,92 @@
+"""GPU parity of the device-resident frame loop (FrameEngine: one hipGraph per frame)
+against the reference fixture and the CPU oracle: greedy ids identical, except behind a
+pick whose top-2 margin in the oracle is at most MARGIN_TOL (bf16 tie / near-tie)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import qtts_oracle as O
+from helpers import golden_weights, load_npz, oracle_cfgs
+
+pytestmark = pytest.mark.gpu
+MARGIN_TOL = 0.0625
+
+
+def greedy(max_tokens, temperature=1.0):
+    from nano_qwen3tts_vllm.sampling_params import SamplingParams
+    return SamplingParams(temperature=temperature, max_tokens=max_tokens, do_sample=False)
+
+
+def assert_ids(got, want, pick_margins):
+    S, NF = want.shape[:2]
+    for i in range(S):
+        for f in range(NF):
+            if not np.array_equal(got[i, f], want[i, f]):
+                assert float(pick_margins[i, :f + 1].min()) <= MARGIN_TOL, \
+                    f"stream {i} frame {f}: {got[i, f].tolist()} != {want[i, f].tolist()} with margins {pick_margins[i, :f + 1]}"
+                break
+
+
+@pytest.mark.parametrize("size,seed,tag", [("tiny", 11, "tiny"), ("tiny-id", 12, "tiny_id")])
+@pytest.mark.parametrize("eager", [False, True])
+def test_frame_engine_matches_fixture(tmp_path, size, seed, tag, eager):
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    g = load_npz(f"model_{tag}.npz")
+    cfg, sd, tw, pw = golden_weights(size, seed)
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    S, NF = 2, 6
+    prompts = [torch.from_numpy(g[f"f_prompt{i}"]) for i in range(S)]
+    text_adds = torch.from_numpy(g["f_text_adds"])
+    fe = FrameEngine(str(tmp_path), max_streams=4, max_text_frames=8, talker_weights=tw, predictor_weights=pw,
+                     enforce_eager=eager, num_kvcache_blocks=8, max_num_batched_tokens=1024, codec_eos=None)
+    for i in range(S):
+        fe.add_stream(prompts[i], text_adds[i], max_frames=NF, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+    got = fe.run_frames(NF).permute(1, 0, 2)[:S].numpy()
+    tc, pc = oracle_cfgs(cfg)
+    want, _, pick_margins = O.frame_loop(tw, tc, pw, pc, prompts, text_adds, NF)
+    assert np.array_equal(want.numpy(), g["f_frames"])           # the oracle itself is pinned to the reference
+    assert_ids(got, want.numpy(), pick_margins.numpy())
+    fe.exit()
+
+
+def test_frame_engine_step_eos_and_late_join(tmp_path):
+    """step(): a stream ends when the talker emits the codec EOS id; a stream admitted later
+    joins the running batch without disturbing the others (ids equal a solo run)."""
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    cfg, sd, tw, pw = golden_weights("tiny", 11)
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(5)
+    H = cfg["talker_config"]["hidden_size"]
+    pa, pb = torch.randn(9, H, generator=gen) * 0.5, torch.randn(300, H, generator=gen) * 0.5
+    ta, tb = torch.randn(12, H, generator=gen) * 0.3, torch.randn(12, H, generator=gen) * 0.3
+    kw = dict(max_streams=4, max_text_frames=16, talker_weights=tw, predictor_weights=pw, num_kvcache_blocks=12,
+              max_num_batched_tokens=1024)
+
+    def solo(prompt, text, n):
+        fe = FrameEngine(str(tmp_path), codec_eos=None, **kw)
+        fe.add_stream(prompt, text, max_frames=n, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+        out = fe.run_frames(n)[:, 0].tolist()
+        fe.exit()
+        return out
+
+    solo_a, solo_b = solo(pa, ta, 8), solo(pb, tb, 5)
+    eos = solo_a[5][0]                       # make stream a end at its 6th frame
+    fe = FrameEngine(str(tmp_path), codec_eos=eos, **kw)
+    a = fe.add_stream(pa, ta, max_frames=8, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+    got_a, got_b, b = [], [], None
+    for f in range(8):
+        if f == 3:
+            b = fe.add_stream(pb, tb, max_frames=5, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+        res = fe.step()
+        if a in res:
+            got_a.append(res[a])
+        if b is not None and b in res:
+            got_b.append(res[b])
+    first_eos = next(i for i, fr in enumerate(solo_a) if fr[0] == eos)
+    assert got_a == solo_a[:first_eos]        # frames before the EOS frame, EOS frame not yielded
+    assert got_b == solo_b[:len(got_b)] and len(got_b) == 5
+    assert a not in fe.streams
+    fe.exit()

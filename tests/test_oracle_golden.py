@@ -63,6 +63,6 @@ def test_models_bit_exact(size, seed, tag):
 
     # frame loop (talker -> predictor burst -> fp32 glue -> talker)
     prompts = [torch.from_numpy(g[f"f_prompt{i}"]) for i in range(2)]
-    frames, margins = O.frame_loop(tw, tc, pw, pc, prompts, torch.from_numpy(g["f_text_adds"]), 6)
+    frames, margins, _ = O.frame_loop(tw, tc, pw, pc, prompts, torch.from_numpy(g["f_text_adds"]), 6)
     assert np.array_equal(frames.numpy(), g["f_frames"])
     assert np.allclose(margins.numpy(), g["f_margins"])
