@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--streams", type=int, default=8)
     ap.add_argument("--size", default="1.7B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=40)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

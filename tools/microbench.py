@@ -1,0 +1,136 @@
+"""GPU microbenchmarks used while tuning (not part of the product path).
+  python tools/microbench.py launch     # per-launch cost of trivial kernels, eager vs graph
+  python tools/microbench.py linear     # skinny-GEMM sweep at the model's shapes
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nano_qwen3tts_vllm import hip
+
+dev = torch.device("cuda", 0)
+
+
+def timed(fn, n_inner, reps=5):
+    s = torch.cuda.Stream()
+    best = 1e9
+    with torch.cuda.stream(s):
+        fn()
+        s.synchronize()
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / n_inner)
+    return best
+
+
+def launch():
+    st = {k: torch.zeros(64, dtype=torch.int32, device=dev) for k in "abc"}
+    pos = torch.zeros(64, dtype=torch.int64, device=dev)
+    tab = torch.zeros(64 * 4, dtype=torch.int32, device=dev)
+    x = torch.randn(8, 2048, device=dev).bfloat16()
+    w = torch.ones(2048, device=dev).bfloat16()
+    y = torch.empty_like(x)
+
+    def adv():
+        hip.check(hip.lib.qtts_advance_decode(hip.ptr(pos), hip.ptr(st["a"]), hip.ptr(st["b"]), hip.ptr(tab), 4, None, None,
+                                              1024, 8, hip.stream()))
+
+    def rms():
+        hip.check(hip.lib.qtts_rmsnorm(hip.ptr(x), 2048, hip.ptr(w), 1e-6, hip.ptr(y), 2048, 8, 2048, hip.stream()))
+
+    for name, k in (("advance(1 WG)", adv), ("rmsnorm(8 WG)", rms)):
+        n = 500
+        eager = timed(lambda: [k() for _ in range(n)], n)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            k()
+            g = hip.Graph.capture(lambda: [k() for _ in range(n)])
+        graph = timed(lambda: g.launch(), n)
+        print(f"{name:16s} eager {eager:6.2f} us/launch   graph {graph:6.2f} us/launch", flush=True)
+
+
+def linear():
+    B = 8
+    shapes = [("qkv 1.7B", 4096, 2048, True, False), ("o 1.7B", 2048, 2048, False, False),
+              ("gate_up 1.7B", 12288, 2048, True, True), ("down 1.7B", 2048, 6144, False, False),
+              ("qkv pred", 4096, 1024, True, False), ("o pred", 1024, 2048, False, False),
+              ("gate_up pred", 6144, 1024, True, True), ("down pred", 1024, 3072, False, False),
+              ("head talker", 3072, 2048, False, False), ("head pred", 2048, 1024, False, False)]
+    for name, N, K, norm, silu in shapes:
+        nbuf = max(2, int(600e6 // (N * K * 2)))
+        ws = [torch.randn(N * K, device=dev).bfloat16() * 0.02 for _ in range(nbuf)]
+        x = torch.randn(B, K, device=dev).bfloat16()
+        nw = torch.ones(K, device=dev).bfloat16()
+        out = torch.empty(B, N // 2 if silu else N, dtype=torch.bfloat16, device=dev)
+        res = torch.randn(B, N, device=dev).bfloat16()
+        line = f"{name:14s} N={N:5d} K={K:5d} {N*K*2/1e6:6.1f} MB:"
+        for ksw, t in ((0, 0), (4, 0), (8, 2), (4, 2), (2, 0), (12, 0), (6, 0)):
+            hip.lib.qtts_tune_linear(ksw, t)
+
+            def run():
+                for w in ws:
+                    if silu:
+                        hip.linear_swiglu(x, w, N // 2, norm_w=nw, out=out)
+                    else:
+                        hip.linear(x, w, N, norm_w=nw if norm else None, residual=None if norm else res, out=out)
+            try:
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    run()
+                    gr = hip.Graph.capture(run)
+                us = timed(lambda: gr.launch(), nbuf)
+                line += f"  ksw{ksw}/t{t}: {us:5.1f}us {N*K*2/us/1e6:5.2f}TB/s"
+            except Exception as e:
+                line += f"  ksw{ksw}/t{t}: n/a"
+        hip.lib.qtts_tune_linear(0, 0)
+        print(line, flush=True)
+
+
+def frame():
+    import json, tempfile
+    sys.path.insert(0, ROOT)
+    import bench
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    from nano_qwen3tts_vllm.sampling_params import SamplingParams
+    from nano_qwen3tts_vllm.utils import synthetic
+    cfg = synthetic.make_config("1.7B")
+    tw, pw = bench.make_weights(cfg, dev)
+    d = tempfile.mkdtemp()
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+    B = 8
+    fe = FrameEngine(d, max_streams=B, max_text_frames=64, talker_weights=tw, predictor_weights=pw,
+                     num_kvcache_blocks=4 * B, max_num_batched_tokens=4096, codec_eos=None)
+    sp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
+    for i in range(B):
+        fe.add_stream(torch.randn(100, 2048, device=dev) * 0.5, torch.randn(8, 2048, device=dev) * 0.1, 60, sp,
+                      SamplingParams(temperature=0.9, max_tokens=17, do_sample=False))
+    fe.run_frames(3)
+    tr, pr = fe.tr, fe.pr
+    st, mb = tr.dstage, tr.max_blocks_per_seq
+
+    def talker_body():
+        tr.decoder.forward(fe.next_x[:B], st.d("positions")[:B], st.d("slots")[:B], st.d("ctx")[:B],
+                           st.d("tables")[:B * mb].view(B, mb), 256, out=fe.cur_hidden[:B])
+
+    def burst_body():
+        pr._burst_body(B)
+
+    for name, body, nk in (("talker 28 layers", talker_body, 1), ("predictor burst", burst_body, 1),
+                           ("whole frame", lambda: fe._frame_body(B, 256), 1)):
+        with torch.cuda.stream(tr.stream):
+            body()
+            g = hip.Graph.capture(body)
+            us = timed(lambda: g.launch(), 1)
+        print(f"{name:18s} {us:8.1f} us per graph launch", flush=True)
+
+
+if __name__ == "__main__":
+    {"launch": launch, "linear": linear, "frame": frame}[sys.argv[1]]()
