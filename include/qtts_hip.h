@@ -67,6 +67,22 @@ int qtts_linear_swiglu(const void *x, int ldx, const void *w_gate_up_packed,
                        const void *norm_w, float eps, void *out, int ldo,
                        int M, int I, int K, qtts_stream_t stream);
 
+/* The decoder stack's GEMM with its fusions (same arithmetic and rounding points as
+ * the calls above, one launch):
+ *   gather_ids != NULL : row m of x is x[gather_ids[m]] (an embedding table as input,
+ *                        P/models/qwen3_tts_predictor.py:94-95 feeding :106);
+ *   norm_w != NULL     : RMSNorm prologue; if xnorm_out != NULL the normalised rows are
+ *                        also written there (the post-final-norm hidden state,
+ *                        P/models/qwen3_tts_talker.py:61, when the GEMM is the codec head);
+ *   swiglu_input != 0  : x is [M, 2K] = [gate | up] and the GEMM consumes
+ *                        silu(gate)*up (P/models/qwen3_tts_share.py:131-135), i.e. the
+ *                        activation is applied on the way into down_proj.
+ * out = bf16(bf16(acc + bias) + residual). */
+int qtts_linear_fused(const void *x, int ldx, const int64_t *gather_ids, int gather_rows,
+                      const void *w_packed, const void *bias, const void *residual, int ldr,
+                      const void *norm_w, float eps, void *xnorm_out, int ldxn, int swiglu_input,
+                      void *out, int ldo, int M, int N, int K, qtts_stream_t stream);
+
 /* y = rmsnorm(x) * w  (P/layers/layernorm.py:17-27).  x,y [M,H]. */
 int qtts_rmsnorm(const void *x, int ldx, const void *w, float eps, void *y, int ldy,
                  int M, int H, qtts_stream_t stream);
@@ -101,6 +117,18 @@ int qtts_paged_attention(const void *q, int ldq, const void *k_cache, const void
                          const int32_t *context_lens, int max_context, float scale,
                          void *out, int ldo, int N, int Hq, int Hkv, void *workspace,
                          qtts_stream_t stream);
+
+/* Decode-step attention block in one launch (P/models/qwen3_tts_share.py:96-106 with
+ * P/layers/attention.py:73-96 in decode mode): per-head RMSNorm + RoPE of q and k read
+ * from the raw qkv rows, the new token's K/V stored at slot_mapping[b], attention of
+ * row b over context_lens[b] tokens of block_tables[b] (the newest from registers).
+ * One row per sequence.  workspace as for qtts_paged_attention. */
+int qtts_attention_decode_fused(const void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w,
+                                float eps, const void *rope_cos, const void *rope_sin, int max_pos,
+                                const int64_t *positions, const int32_t *slot_mapping, void *k_cache,
+                                void *v_cache, const int32_t *block_tables, int max_blocks,
+                                const int32_t *context_lens, int max_context, float scale, void *out,
+                                int ldo, int B, int Hq, int Hkv, void *workspace, qtts_stream_t stream);
 
 /* Greedy pick: out[i] = argmax_j float(logits[i,j]), lowest j on ties (the build's
  * do_sample=False path; P/sampling_params.py:9 carries the flag). */
@@ -159,6 +187,8 @@ typedef struct qtts_model qtts_model_t;
 qtts_model_t *qtts_model_create(int hidden, int n_layers, int n_heads, int n_kv_heads,
                                 int head_dim, int intermediate, float rms_eps);
 void qtts_model_destroy(qtts_model_t *m);
+/* wqkv_packed = qtts_pack_weight of [q_proj; k_proj; v_proj] rows, w_gate_up_packed =
+ * qtts_pack_weight of [gate_proj; up_proj] rows (plain concatenation). */
 int qtts_model_set_layer(qtts_model_t *m, int layer, const void *input_norm_w,
                          const void *wqkv_packed, const void *q_norm_w, const void *k_norm_w,
                          const void *wo_packed, const void *post_norm_w,
@@ -178,6 +208,14 @@ int qtts_model_forward(qtts_model_t *m, const void *x, const int64_t *positions,
                        const int32_t *slot_mapping, const int32_t *row_seq,
                        const int32_t *context_lens, const int32_t *block_tables, int max_blocks,
                        int max_context, int N, void *hidden_out, qtts_stream_t stream);
+/* Same, with the output head folded in: logits_out[N,vocab] = head(final_norm(layers(x)))
+ * and hidden_out = final_norm(layers(x)) from the head GEMM's prologue
+ * (compute_logits, P/models/qwen3_tts_talker.py:131-136 / qwen3_tts_predictor.py:110-124). */
+int qtts_model_forward_logits(qtts_model_t *m, const void *x, const int64_t *positions,
+                              const int32_t *slot_mapping, const int32_t *row_seq,
+                              const int32_t *context_lens, const int32_t *block_tables, int max_blocks,
+                              int max_context, int N, void *hidden_out, const void *head_w_packed,
+                              int vocab, void *logits_out, qtts_stream_t stream);
 
 /* ---------------------------------------------------------------- hipGraph helpers
  * Capture a sequence of the calls above once per batch size and replay it

@@ -311,6 +311,237 @@ extern "C" int qtts_linear_swiglu(const void *x, int ldx, const void *w_gate_up_
                          (hipStream_t)stream);
 }
 
+
+// ------------------------------------------------------------------ linear v2 (decoder stack GEMM)
+// One kernel shape for every projection of the decoder stack.  Workgroup = NW <= 8 waves, wave w owns
+// k-steps [w*KSW, (w+1)*KSW); the workgroup walks `tiles_per_wg` consecutive 16-row weight tiles, the
+// next tile's fragments already in flight (double buffer) while the current tile is multiplied, reduced
+// across waves through LDS and written by wave 0.  Activation prologues (PRO):
+//   0  x as is (optionally gathered rows: x row m = x[ids[m]])
+//   1  RMSNorm(x) * norm_w, the reference's rounding points; blockIdx.x == 0 may write the normalised rows
+//   2  x holds [gate | up] (2K columns): silu(gate) -> bf16, * up -> bf16 (the MLP activation, moved from the
+//      producing GEMM's epilogue into the consuming GEMM's prologue so that every GEMM is plain tiles)
+struct LinArgs {
+    const bf16_t *x; int ldx;
+    const int64_t *ids; int id_rows;
+    const uint4 *wp;
+    const bf16_t *bias, *res; int ldr;
+    const bf16_t *nw; float eps;
+    bf16_t *xnorm_out; int ldxn;
+    bf16_t *out; int ldo;
+    int M, N, K, tiles_per_wg;
+};
+
+__device__ __forceinline__ void unpack2(uint32_t w, float &a, float &b) {
+    a = __uint_as_float(w << 16);
+    b = __uint_as_float(w & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+}
+
+template <int KSW, int PRO, bool DB>
+__global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
+    extern __shared__ float4_t smem4[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int KS = p.K >> 5;
+    const int m = blockIdx.y * 16 + r;
+    const bool mvalid = m < p.M;
+    const int ks0 = wave * KSW;
+    const int ntiles = p.N >> 4;
+    const int t_begin = blockIdx.x * p.tiles_per_wg;
+    const int t_end = min(t_begin + p.tiles_per_wg, ntiles);
+
+    Frag a[DB ? 2 : 1][KSW];
+    {
+        const uint4 *wptr = p.wp + ((size_t)t_begin * KS + ks0) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) a[0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
+    }
+
+    // ---- activation prologue
+    Frag xb[KSW];
+    size_t xrow = 0;
+    if (mvalid) {
+        long rid = m;
+        if (p.ids) {
+            rid = p.ids[m];
+            rid = rid < 0 ? 0 : (rid >= p.id_rows ? p.id_rows - 1 : rid);
+        }
+        xrow = (size_t)rid * p.ldx;
+    }
+#pragma unroll
+    for (int i = 0; i < KSW; ++i) {
+        const int k = 32 * (ks0 + i) + 8 * g;
+        if (!mvalid) {
+            xb[i].u = make_uint4(0, 0, 0, 0);
+        } else if (PRO == 2) {
+            Frag ga, up;
+            ga.u = *reinterpret_cast<const uint4 *>(p.x + xrow + k);
+            up.u = *reinterpret_cast<const uint4 *>(p.x + xrow + p.K + k);
+            uint32_t gw[4] = {ga.u.x, ga.u.y, ga.u.z, ga.u.w}, uw[4] = {up.u.x, up.u.y, up.u.z, up.u.w}, ow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float g0, g1, u0, u1;
+                unpack2(gw[j], g0, g1);
+                unpack2(uw[j], u0, u1);
+                const float s0 = rbf(g0 / (1.0f + expf(-g0))), s1 = rbf(g1 / (1.0f + expf(-g1)));
+                ow[j] = pack2(s0 * u0, s1 * u1);
+            }
+            xb[i].u = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        } else {
+            xb[i].u = *reinterpret_cast<const uint4 *>(p.x + xrow + k);
+        }
+    }
+    float *normred = reinterpret_cast<float *>(smem4 + (size_t)2 * NW * 64);
+    if (PRO == 1) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) {
+            const uint32_t w4[4] = {xb[i].u.x, xb[i].u.y, xb[i].u.z, xb[i].u.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v0, v1;
+                unpack2(w4[j], v0, v1);
+                ss += v0 * v0;
+                ss += v1 * v1;
+            }
+        }
+        ss += __shfl_xor(ss, 16);
+        ss += __shfl_xor(ss, 32);
+        if (g == 0) normred[wave * 16 + r] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (int w = 0; w < NW; ++w) tot += normred[w * 16 + r];
+        const float rstd = 1.0f / sqrtf(tot / (float)p.K + p.eps);
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) {
+            const int k = 32 * (ks0 + i) + 8 * g;
+            const uint4 wv = *reinterpret_cast<const uint4 *>(p.nw + k);
+            const uint32_t x4[4] = {xb[i].u.x, xb[i].u.y, xb[i].u.z, xb[i].u.w}, w4[4] = {wv.x, wv.y, wv.z, wv.w};
+            uint32_t o4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v0, v1, w0, w1;
+                unpack2(x4[j], v0, v1);
+                unpack2(w4[j], w0, w1);
+                o4[j] = pack2(rbf(v0 * rstd) * w0, rbf(v1 * rstd) * w1);
+            }
+            xb[i].u = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            if (p.xnorm_out && blockIdx.x == 0 && mvalid)
+                *reinterpret_cast<uint4 *>(p.xnorm_out + (size_t)m * p.ldxn + k) = xb[i].u;
+        }
+    }
+
+    // ---- tile loop
+    auto tile_body = [&](const int cur, const int t, const int it) {
+        if (DB && t + 1 < t_end) {
+            const uint4 *wptr = p.wp + ((size_t)(t + 1) * KS + ks0) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < KSW; ++i)
+                a[DB ? (cur ^ 1) : 0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
+        }
+        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KSW; ++i)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[DB ? cur : 0][i].v, xb[i].v, acc, 0, 0, 0);
+        float4_t *red = smem4 + (size_t)(it & 1) * NW * 64;
+        red[wave * 64 + lane] = acc;
+        __syncthreads();
+        if (wave == 0) {
+            float4_t sum = red[lane];
+            for (int w = 1; w < NW; ++w) sum += red[w * 64 + lane];
+            const int n = 16 * t + 4 * g;
+            if (mvalid) {
+                uint32_t o2[2];
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float q = sum[j];
+                    if (p.bias) q += bf2f(p.bias[n + j]);
+                    q = rbf(q);
+                    if (p.res) q = q + bf2f(p.res[(size_t)m * p.ldr + n + j]);
+                    v[j] = q;
+                }
+                o2[0] = pack2(v[0], v[1]);
+                o2[1] = pack2(v[2], v[3]);
+                *reinterpret_cast<uint2 *>(p.out + (size_t)m * p.ldo + n) = make_uint2(o2[0], o2[1]);
+            }
+        }
+    };
+    int it = 0;
+    for (int t = t_begin; t < t_end; t += 2, it += 2) {
+        tile_body(0, t, it);
+        if (t + 1 < t_end) tile_body(1, t + 1, it + 1);
+    }
+}
+
+template <int KSW, int PRO, bool DB>
+static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs &a) {
+    size_t shmem = (size_t)2 * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
+    hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB>), grid, dim3(NW * 64), shmem, s, a);
+}
+
+static int launch_linear2(LinArgs a, int pro, hipStream_t s) {
+    QCHECK(a.x && a.wp && a.out, "linear: null pointer");
+    QCHECK(a.M > 0 && a.N > 0 && a.K > 0, "linear: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    QCHECK(a.N % 16 == 0 && a.K % 32 == 0, "linear: need N%%16==0 and K%%32==0 (N=%d K=%d)", a.N, a.K);
+    QCHECK(a.ldx % 8 == 0 && a.ldx >= (pro == 2 ? 2 * a.K : a.K), "linear: x row stride %d too small or not a multiple of 8", a.ldx);
+    QCHECK(a.ldo % 4 == 0 && a.ldo >= a.N, "linear: bad out row stride %d", a.ldo);
+    QCHECK(!a.res || a.ldr >= a.N, "linear: residual row stride %d < N", a.ldr);
+    QCHECK(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.wp & 15) == 0 && ((uintptr_t)a.out & 7) == 0, "linear: misaligned pointer");
+    QCHECK(pro != 1 || a.nw, "linear: norm prologue without weight");
+    QCHECK(!a.xnorm_out || (a.ldxn % 8 == 0 && a.ldxn >= a.K), "linear: bad xnorm_out stride");
+    const int KS = a.K / 32;
+    static const int ksws[] = {1, 2, 4, 6, 8, 12, 24};
+    int KSW = 0;
+    for (int c : ksws)
+        if (KS % c == 0 && KS / c <= 8) { KSW = c; break; }
+    if (g_tune_ksw > 0 && KS % g_tune_ksw == 0 && KS / g_tune_ksw <= 8)
+        for (int c : ksws) if (c == g_tune_ksw) KSW = c;
+    QCHECK(KSW > 0, "linear: K=%d not supported (K/32 must factor as <=8 waves x {1,2,4,6,8,12,24})", a.K);
+    QCHECK(!(pro == 1 && KSW == 24), "linear: RMSNorm prologue not supported for K=%d", a.K);
+    const int NW = KS / KSW;
+    const int ntiles = a.N / 16;
+    const bool db = KSW <= 12;
+    int tpw = 1;
+    if (db) {
+        const int target = g_tune_t > 0 ? g_tune_t * 256 : 256;
+        tpw = (ntiles + target - 1) / target;
+    }
+    a.tiles_per_wg = tpw;
+    dim3 grid((ntiles + tpw - 1) / tpw, (a.M + 15) / 16);
+#define QL2(KSW_, DB_) case KSW_: \
+        if (pro == 0) launch_linear2_inst<KSW_, 0, DB_>(grid, NW, s, a); \
+        else if (pro == 1) launch_linear2_inst<KSW_, 1, DB_>(grid, NW, s, a); \
+        else launch_linear2_inst<KSW_, 2, DB_>(grid, NW, s, a); \
+        break;
+    switch (KSW) {
+        QL2(1, true) QL2(2, true) QL2(4, true) QL2(6, true) QL2(8, true) QL2(12, true) QL2(24, false)
+        default: QFAIL(QTTS_EINVAL, "linear: unsupported KSW %d", KSW);
+    }
+#undef QL2
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+extern "C" int qtts_linear_fused(const void *x, int ldx, const int64_t *gather_ids, int gather_rows,
+                                 const void *w_packed, const void *bias, const void *residual, int ldr,
+                                 const void *norm_w, float eps, void *xnorm_out, int ldxn, int swiglu_input,
+                                 void *out, int ldo, int M, int N, int K, qtts_stream_t stream) {
+    QCHECK(!(swiglu_input && norm_w), "linear_fused: swiglu_input and norm_w are exclusive");
+    QCHECK(!gather_ids || gather_rows > 0, "linear_fused: gather without a row count");
+    LinArgs a;
+    a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = gather_ids; a.id_rows = gather_rows;
+    a.wp = (const uint4 *)w_packed; a.bias = (const bf16_t *)bias; a.res = (const bf16_t *)residual; a.ldr = ldr;
+    a.nw = (const bf16_t *)norm_w; a.eps = eps; a.xnorm_out = (bf16_t *)xnorm_out; a.ldxn = ldxn;
+    a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.tiles_per_wg = 1;
+    return launch_linear2(a, swiglu_input ? 2 : (norm_w ? 1 : 0), (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ rmsnorm (stand-alone)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t *__restrict__ x, int ldx, const bf16_t *__restrict__ w,
                                                       float eps, bf16_t *__restrict__ y, int ldy, int H) {
@@ -358,7 +589,7 @@ extern "C" int qtts_rmsnorm(const void *x, int ldx, const void *w, float eps, vo
 __global__ __launch_bounds__(64) void qknorm_rope_store_kernel(
     bf16_t *__restrict__ qkv, int ld, const bf16_t *__restrict__ qw, const bf16_t *__restrict__ kw, float eps,
     const bf16_t *__restrict__ cosT, const bf16_t *__restrict__ sinT, const int64_t *__restrict__ positions,
-    const int32_t *__restrict__ slots, bf16_t *__restrict__ kc, bf16_t *__restrict__ vc, int Hq, int Hkv) {
+    const int32_t *__restrict__ slots, bf16_t *__restrict__ kc, bf16_t *__restrict__ vc, int Hq, int Hkv, int max_pos) {
     const int tok = blockIdx.x, head = blockIdx.y, i = threadIdx.x;
     bf16_t *p = qkv + (size_t)tok * ld + (size_t)head * 128;
     const int slot = slots ? slots[tok] : -1;
@@ -378,7 +609,8 @@ __global__ __launch_bounds__(64) void qknorm_rope_store_kernel(
     const float rstd = 1.0f / sqrtf(ss / 128.0f + eps);
     const float n0 = rbf(rbf(x0 * rstd) * bf2f(w[i]));
     const float n1 = rbf(rbf(x1 * rstd) * bf2f(w[i + 64]));
-    const long pos = positions[tok];
+    long pos = positions[tok];
+    pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);          // metadata is device data: never index past the table
     const float c = bf2f(cosT[pos * 64 + i]), s = bf2f(sinT[pos * 64 + i]);
     // q*cos + rotate_half(q)*sin, each op rounded to bf16
     const bf16_t o0 = f2bf(rbf(n0 * c) + rbf(-n1 * s));
@@ -402,7 +634,7 @@ extern "C" int qtts_qknorm_rope_store(void *qkv, int ldqkv, const void *q_norm_w
     hipLaunchKernelGGL(qknorm_rope_store_kernel, dim3(N, Hq + 2 * Hkv), dim3(64), 0, (hipStream_t)stream,
                        (bf16_t *)qkv, ldqkv, (const bf16_t *)q_norm_w, (const bf16_t *)k_norm_w, eps,
                        (const bf16_t *)rope_cos, (const bf16_t *)rope_sin, positions, slot_mapping, (bf16_t *)k_cache,
-                       (bf16_t *)v_cache, Hq, Hkv);
+                       (bf16_t *)v_cache, Hq, Hkv, max_pos);
     QLAUNCH();
     return QTTS_OK;
 }
@@ -558,14 +790,15 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(
 __global__ __launch_bounds__(128) void attn_combine_kernel(const float *__restrict__ part_o,
                                                            const float *__restrict__ part_ml,
                                                            const int32_t *__restrict__ context_lens,
-                                                           bf16_t *__restrict__ out, int ldo, int Hq, int nsplit) {
+                                                           bf16_t *__restrict__ out, int ldo, int Hq, int nsplit,
+                                                           int split_tokens) {
     const int row = blockIdx.x, hq = blockIdx.y, d = threadIdx.x;
     const int ctx = context_lens[row];
     if (ctx <= 0) {
         out[(size_t)row * ldo + (size_t)hq * 128 + d] = 0;
         return;
     }
-    const int ns = (ctx + ATT_SPLIT - 1) / ATT_SPLIT;
+    const int ns = (ctx + split_tokens - 1) / split_tokens;
     const size_t p0 = ((size_t)row * Hq + hq) * nsplit;
     float M = -INFINITY;
     for (int s = 0; s < ns; ++s) M = fmaxf(M, part_ml[(p0 + s) * 2]);
@@ -613,7 +846,250 @@ extern "C" int qtts_paged_attention(const void *q, int ldq, const void *k_cache,
     QLAUNCH();
     if (ns > 1) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3(N, Hq), dim3(128), 0, s, part_o, part_ml, context_lens,
-                           (bf16_t *)out, ldo, Hq, ns);
+                           (bf16_t *)out, ldo, Hq, ns, ATT_SPLIT);
+        QLAUNCH();
+    }
+    return QTTS_OK;
+}
+
+
+// ------------------------------------------------------------------ decode attention with fused q/k norm, RoPE, KV store
+// One query row per sequence (decode).  Reads the raw q/k/v rows the qkv GEMM produced, applies the
+// per-head RMSNorm and rotary embedding in registers (same rounding points as qknorm_rope_store_kernel),
+// stores the new token's K/V into its cache slot and attends over context_lens[row] cached tokens, the
+// newest one taken from registers.  grid (rows, Hkv, nsplit), 256-token splits walked as two 128-token
+// passes; 16 lanes per token, a lane owns 8 head dims (its rotate_half partner is lane ^ 8).
+#define ATT2_SPLIT 256
+struct AttnFusedArgs {
+    const bf16_t *qkv; int ld;
+    const bf16_t *qw, *kw; float eps;
+    const bf16_t *cosT, *sinT; int max_pos;
+    const int64_t *positions;
+    const int32_t *slots;
+    bf16_t *kc, *vc;
+    const int32_t *block_tables; int max_blocks;
+    const int32_t *context_lens;
+    float scale;
+    bf16_t *out; int ldo;
+    int Hq, Hkv;
+    float *part_o, *part_ml; int nsplit;
+};
+
+__device__ __forceinline__ void norm_rope8(const float (&x)[8], const bf16_t *__restrict__ w, float eps, int l16,
+                                           const bf16_t *__restrict__ cosr, const bf16_t *__restrict__ sinr, float (&o)[8]) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    ss += __shfl_xor(ss, 4);
+    ss += __shfl_xor(ss, 8);
+    const float rstd = 1.0f / sqrtf(ss / 128.0f + eps);
+    const int d0 = 8 * l16;
+    const bool hi = l16 >= 8;                         // dims 64..127
+    Frag wv, cv, sv;
+    wv.u = *reinterpret_cast<const uint4 *>(w + d0);
+    cv.u = *reinterpret_cast<const uint4 *>(cosr + (d0 & 63));
+    sv.u = *reinterpret_cast<const uint4 *>(sinr + (d0 & 63));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float n = rbf(rbf(x[j] * rstd) * bf2f(wv.h[j]));
+        const float partner = __shfl_xor(n, 8);       // the element 64 dims away
+        const float c = bf2f(cv.h[j]), sn = bf2f(sv.h[j]);
+        o[j] = rbf(rbf(n * c) + rbf((hi ? partner : -partner) * sn));
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnFusedArgs p) {
+    __shared__ float sm_acc[16][G][128];
+    __shared__ float sm_m[16][G];
+    __shared__ float sm_l[16][G];
+    const int row = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
+    const int ctx = p.context_lens[row];
+    const int Hq = p.Hq, Hkv = p.Hkv;
+    const int t0 = split * ATT2_SPLIT;
+    if (ctx <= 0) {
+        if (split == 0 && p.nsplit == 1)
+            for (int e = threadIdx.x; e < G * 128; e += 256) p.out[(size_t)row * p.ldo + (size_t)kvh * G * 128 + e] = 0;
+        return;
+    }
+    if (t0 >= ctx) return;
+    const int32_t *bt = p.block_tables + (size_t)row * p.max_blocks;
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const bf16_t *rowp = p.qkv + (size_t)row * p.ld;
+    long pos = p.positions[row];
+    pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);      // metadata is device data: never index past the table
+    const bf16_t *cosr = p.cosT + pos * 64, *sinr = p.sinT + pos * 64;
+
+    // cached K/V of the first pass are requested before the norm/rope arithmetic
+    Frag kk[8], vv[8];
+    auto issue_loads = [&](int base) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = base + i * 16 + grp;
+            if (t < ctx - 1) {
+                const int blk = bt[t >> 8];
+                const size_t off = (((size_t)blk * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
+                kk[i].u = *reinterpret_cast<const uint4 *>(p.kc + off);
+                vv[i].u = *reinterpret_cast<const uint4 *>(p.vc + off);
+            } else {
+                kk[i].u = make_uint4(0, 0, 0, 0);
+                vv[i].u = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    issue_loads(t0);
+
+    float qf[G][8];
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+        Frag f;
+        f.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(kvh * G + h) * 128 + 8 * l16);
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = bf2f(f.h[j]);
+        norm_rope8(x, p.qw, p.eps, l16, cosr, sinr, qf[h]);
+    }
+    // the new token (index ctx-1): K normalised + rotated, V as is
+    float knew[8], vnew[8];
+    {
+        Frag f, fv;
+        f.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(Hq + kvh) * 128 + 8 * l16);
+        fv.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(Hq + Hkv + kvh) * 128 + 8 * l16);
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[j] = bf2f(f.h[j]);
+            vnew[j] = bf2f(fv.h[j]);
+        }
+        norm_rope8(x, p.kw, p.eps, l16, cosr, sinr, knew);
+        const int slot = p.slots ? p.slots[row] : -1;
+        if (slot >= 0 && grp == 0 && (ctx - 1) >= t0 && (ctx - 1) < t0 + ATT2_SPLIT) {
+            Frag ko;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ko.h[j] = f2bf(knew[j]);
+            const size_t off = ((size_t)slot * Hkv + kvh) * 128 + 8 * l16;
+            *reinterpret_cast<uint4 *>(p.kc + off) = ko.u;
+            *reinterpret_cast<uint4 *>(p.vc + off) = fv.u;
+        }
+    }
+
+    float mx[G], ls[G], acc[G][8];
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+        mx[h] = -INFINITY;
+        ls[h] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        const int base = t0 + pass * 128;
+        if (base >= ctx) break;
+        if (pass == 1) issue_loads(base);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = base + i * 16 + grp;
+            const bool valid = t < ctx;
+            const bool is_new = t == ctx - 1;
+            float kf[8], vf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                kf[j] = is_new ? knew[j] : bf2f(kk[i].h[j]);
+                vf[j] = is_new ? vnew[j] : bf2f(vv[i].h[j]);
+            }
+#pragma unroll
+            for (int h = 0; h < G; ++h) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += qf[h][j] * kf[j];
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                s += __shfl_xor(s, 8);
+                s *= p.scale;
+                if (valid) {
+                    const float mn = fmaxf(mx[h], s);
+                    const float corr = __expf(mx[h] - mn);
+                    const float pr = __expf(s - mn);
+                    ls[h] = ls[h] * corr + pr;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[h][j] = acc[h][j] * corr + pr * vf[j];
+                    mx[h] = mn;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sm_acc[grp][h][8 * l16 + j] = acc[h][j];
+        if (l16 == 0) {
+            sm_m[grp][h] = mx[h];
+            sm_l[grp][h] = ls[h];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < G * 128; e += 256) {
+        const int h = e >> 7, d = e & 127;
+        float M = -INFINITY;
+#pragma unroll
+        for (int gI = 0; gI < 16; ++gI) M = fmaxf(M, sm_m[gI][h]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int gI = 0; gI < 16; ++gI) {
+            const float wgt = __expf(sm_m[gI][h] - M);
+            L += sm_l[gI][h] * wgt;
+            o += sm_acc[gI][h][d] * wgt;
+        }
+        const int hq = kvh * G + h;
+        if (p.nsplit == 1) {
+            p.out[(size_t)row * p.ldo + (size_t)hq * 128 + d] = f2bf(o / L);
+        } else {
+            const size_t pi = ((size_t)row * Hq + hq) * p.nsplit + split;
+            p.part_o[pi * 128 + d] = o;
+            if (d == 0) {
+                p.part_ml[pi * 2 + 0] = M;
+                p.part_ml[pi * 2 + 1] = L;
+            }
+        }
+    }
+}
+
+static inline int attn2_nsplit(int max_context) { return (max_context + ATT2_SPLIT - 1) / ATT2_SPLIT; }
+
+extern "C" int qtts_attention_decode_fused(const void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w,
+                                           float eps, const void *rope_cos, const void *rope_sin, int max_pos,
+                                           const int64_t *positions, const int32_t *slot_mapping, void *k_cache,
+                                           void *v_cache, const int32_t *block_tables, int max_blocks,
+                                           const int32_t *context_lens, int max_context, float scale, void *out,
+                                           int ldo, int B, int Hq, int Hkv, void *workspace, qtts_stream_t stream) {
+    QCHECK(qkv && q_norm_w && k_norm_w && rope_cos && rope_sin && positions && k_cache && v_cache && block_tables &&
+               context_lens && out, "attention_decode_fused: null pointer");
+    QCHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && ldqkv % 8 == 0 && ldqkv >= (Hq + 2 * Hkv) * 128 &&
+               ldo >= Hq * 128, "attention_decode_fused: bad shape");
+    QCHECK(max_pos > 0 && max_blocks > 0 && max_context > 0 && max_context <= max_blocks * QTTS_KV_BLOCK,
+           "attention_decode_fused: bad context bounds");
+    const int ns = attn2_nsplit(max_context);
+    QCHECK(ns == 1 || workspace, "attention_decode_fused: workspace required for contexts > %d", ATT2_SPLIT);
+    AttnFusedArgs a;
+    a.qkv = (const bf16_t *)qkv; a.ld = ldqkv; a.qw = (const bf16_t *)q_norm_w; a.kw = (const bf16_t *)k_norm_w; a.eps = eps;
+    a.cosT = (const bf16_t *)rope_cos; a.sinT = (const bf16_t *)rope_sin; a.max_pos = max_pos; a.positions = positions; a.slots = slot_mapping;
+    a.kc = (bf16_t *)k_cache; a.vc = (bf16_t *)v_cache; a.block_tables = block_tables; a.max_blocks = max_blocks;
+    a.context_lens = context_lens; a.scale = scale; a.out = (bf16_t *)out; a.ldo = ldo; a.Hq = Hq; a.Hkv = Hkv;
+    a.part_o = (float *)workspace; a.part_ml = a.part_o ? a.part_o + (size_t)B * Hq * ns * 128 : nullptr; a.nsplit = ns;
+    dim3 grid(B, Hkv, ns);
+    hipStream_t s = (hipStream_t)stream;
+    switch (Hq / Hkv) {
+        case 1: hipLaunchKernelGGL((attn_decode_fused_kernel<1>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((attn_decode_fused_kernel<2>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<4>), grid, dim3(256), 0, s, a); break;
+        default: QFAIL(QTTS_EINVAL, "attention_decode_fused: unsupported q/kv head ratio %d", Hq / Hkv);
+    }
+    QLAUNCH();
+    if (ns > 1) {
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(B, Hq), dim3(128), 0, s, a.part_o, a.part_ml, context_lens,
+                           (bf16_t *)out, ldo, Hq, ns, ATT2_SPLIT);
         QLAUNCH();
     }
     return QTTS_OK;
@@ -995,7 +1471,7 @@ static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
     const size_t qkvw = (size_t)(m->n_heads + 2 * m->n_kv_heads) * 128;
     L.qkv = off; off += align256((size_t)rows * qkvw * 2);
     L.attn = off; off += align256((size_t)rows * m->n_heads * 128 * 2);
-    L.act = off; off += align256((size_t)rows * m->inter * 2);
+    L.act = off; off += align256((size_t)rows * 2 * m->inter * 2);
     L.xa = off; off += align256((size_t)rows * m->hidden * 2);
     L.xb = off; off += align256((size_t)rows * m->hidden * 2);
     L.att_ws = off; off += align256(qtts_attn_workspace_bytes(rows, m->n_heads, max_context));
@@ -1020,9 +1496,10 @@ extern "C" int qtts_model_set_workspace(qtts_model_t *m, void *ws, size_t bytes,
     return QTTS_OK;
 }
 
-extern "C" int qtts_model_forward(qtts_model_t *m, const void *x, const int64_t *positions, const int32_t *slot_mapping,
-                                  const int32_t *row_seq, const int32_t *context_lens, const int32_t *block_tables,
-                                  int max_blocks, int max_context, int N, void *hidden_out, qtts_stream_t stream) {
+static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *positions, const int32_t *slot_mapping,
+                              const int32_t *row_seq, const int32_t *context_lens, const int32_t *block_tables,
+                              int max_blocks, int max_context, int N, void *hidden_out, const void *head_w, int vocab,
+                              void *logits_out, qtts_stream_t stream) {
     QCHECK(m, "model_forward: null model");
     if (!m->final_norm || !m->cosT || !m->kv || !m->ws) QFAIL(QTTS_ESTATE, "model_forward: model not fully configured");
     for (const LayerW &L : m->layers)
@@ -1044,24 +1521,60 @@ extern "C" int qtts_model_forward(qtts_model_t *m, const void *x, const int64_t 
     const size_t layer_kv = (size_t)m->num_blocks * QTTS_KV_BLOCK * Hkv * 128 * 2;   // bytes per layer per K or V
     const bf16_t *cur = (const bf16_t *)x;
     int rc;
+    const bool decode = row_seq == nullptr;           // one row per sequence: fused norm/RoPE/store/attention
     for (int l = 0; l < m->n_layers; ++l) {
         const LayerW &L = m->layers[l];
         char *kc = m->kv + (size_t)l * layer_kv;
         char *vc = m->kv + ((size_t)m->n_layers + l) * layer_kv;
-        if ((rc = qtts_linear(cur, H, L.wqkv, nullptr, nullptr, 0, L.in_norm, m->eps, qkv, qkvw, N, qkvw, H, stream))) return rc;
-        if ((rc = qtts_qknorm_rope_store(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos, positions,
-                                         slot_mapping, kc, vc, N, Hq, Hkv, stream))) return rc;
-        if ((rc = qtts_paged_attention(qkv, qkvw, kc, vc, block_tables, max_blocks, row_seq, context_lens, max_context,
-                                       scale, attn, Hq * 128, N, Hq, Hkv, att_ws, stream))) return rc;
-        if ((rc = qtts_linear(attn, Hq * 128, L.wo, nullptr, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, stream))) return rc;
-        if ((rc = qtts_linear_swiglu(xa, H, L.wgu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
-        if ((rc = qtts_linear(act, m->inter, L.wdown, nullptr, xa, H, nullptr, 0.f, xb, H, N, H, m->inter, stream))) return rc;
+        if ((rc = qtts_linear_fused(cur, H, nullptr, 0, L.wqkv, nullptr, nullptr, 0, L.in_norm, m->eps, nullptr, 0, 0,
+                                    qkv, qkvw, N, qkvw, H, stream))) return rc;
+        if (decode) {
+            if ((rc = qtts_attention_decode_fused(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
+                                                  positions, slot_mapping, kc, vc, block_tables, max_blocks,
+                                                  context_lens, max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws,
+                                                  stream))) return rc;
+        } else {
+            if ((rc = qtts_qknorm_rope_store(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
+                                             positions, slot_mapping, kc, vc, N, Hq, Hkv, stream))) return rc;
+            if ((rc = qtts_paged_attention(qkv, qkvw, kc, vc, block_tables, max_blocks, row_seq, context_lens,
+                                           max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws, stream))) return rc;
+        }
+        if ((rc = qtts_linear_fused(attn, Hq * 128, nullptr, 0, L.wo, nullptr, cur, H, nullptr, 0.f, nullptr, 0, 0, xa, H,
+                                    N, H, Hq * 128, stream))) return rc;
+        // gate|up columns side by side; the SwiGLU is applied by the down projection's prologue
+        if ((rc = qtts_linear_fused(xa, H, nullptr, 0, L.wgu, nullptr, nullptr, 0, L.post_norm, m->eps, nullptr, 0, 0, act,
+                                    2 * m->inter, N, 2 * m->inter, H, stream))) return rc;
+        if ((rc = qtts_linear_fused(act, 2 * m->inter, nullptr, 0, L.wdown, nullptr, xa, H, nullptr, 0.f, nullptr, 0, 1,
+                                    xb, H, N, H, m->inter, stream))) return rc;
         // Fixed roles: xa = post-attention residual stream, xb = layer output.  The next layer reads xb
         // (qkv GEMM, o_proj residual) before its down_proj overwrites it, all stream-ordered.
         cur = xb;
     }
+    if (head_w) {
+        // final RMSNorm folded into the head GEMM's prologue; the normalised rows are the returned hidden state
+        if ((rc = qtts_linear_fused(cur, H, nullptr, 0, head_w, nullptr, nullptr, 0, m->final_norm, m->eps, hidden_out, H, 0,
+                                    logits_out, vocab, N, vocab, H, stream))) return rc;
+        return QTTS_OK;
+    }
     if ((rc = qtts_rmsnorm(cur, H, m->final_norm, m->eps, hidden_out, H, N, H, stream))) return rc;
     return QTTS_OK;
+}
+
+extern "C" int qtts_model_forward(qtts_model_t *m, const void *x, const int64_t *positions, const int32_t *slot_mapping,
+                                  const int32_t *row_seq, const int32_t *context_lens, const int32_t *block_tables,
+                                  int max_blocks, int max_context, int N, void *hidden_out, qtts_stream_t stream) {
+    return model_forward_impl(m, x, positions, slot_mapping, row_seq, context_lens, block_tables, max_blocks, max_context,
+                              N, hidden_out, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int qtts_model_forward_logits(qtts_model_t *m, const void *x, const int64_t *positions,
+                                         const int32_t *slot_mapping, const int32_t *row_seq,
+                                         const int32_t *context_lens, const int32_t *block_tables, int max_blocks,
+                                         int max_context, int N, void *hidden_out, const void *head_w_packed, int vocab,
+                                         void *logits_out, qtts_stream_t stream) {
+    QCHECK(head_w_packed && logits_out && vocab > 0 && vocab % 16 == 0, "model_forward_logits: bad head arguments");
+    return model_forward_impl(m, x, positions, slot_mapping, row_seq, context_lens, block_tables, max_blocks, max_context,
+                              N, hidden_out, head_w_packed, vocab, logits_out, stream);
 }
 
 // ------------------------------------------------------------------ hipGraph helpers

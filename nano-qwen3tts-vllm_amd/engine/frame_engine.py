@@ -197,9 +197,9 @@ class FrameEngine:
         hip.check(lib.qtts_advance_decode(hip.ptr(st.d("positions")), hip.ptr(st.d("slots")), hip.ptr(st.d("ctx")),
                                           hip.ptr(st.d("tables")), mb, hip.ptr(self.frame_idx), hip.ptr(self.rng),
                                           tr.config.max_model_len, bs, s()), "advance_decode")
-        tr.decoder.forward(self.next_x[:bs], st.d("positions")[:bs], st.d("slots")[:bs], st.d("ctx")[:bs],
-                           st.d("tables")[:bs * mb].view(bs, mb), max_context, out=self.cur_hidden[:bs])
-        hip.linear(self.cur_hidden[:bs], tr.codec_head, tr.vocab, out=tr.logits[:bs])
+        tr.decoder.forward_logits(self.next_x[:bs], st.d("positions")[:bs], st.d("slots")[:bs], st.d("ctx")[:bs],
+                                  st.d("tables")[:bs * mb].view(bs, mb), max_context, tr.codec_head, tr.vocab,
+                                  hidden_out=self.cur_hidden[:bs], logits_out=tr.logits[:bs])
         hip.check(lib.qtts_pick_token(hip.ptr(tr.logits), tr.vocab, hip.ptr(self.temps_t), hip.ptr(self.greedy),
                                       self.top_k, tr.rng_seed, 32, hip.ptr(self.rng), hip.ptr(self.cur_token), 1, bs,
                                       tr.vocab, s()), "pick_token")

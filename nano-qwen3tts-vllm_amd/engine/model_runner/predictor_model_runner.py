@@ -191,13 +191,20 @@ class PredictorModelRunner(ModelRunner):
         off = n0
         for step in range(1, self.n_gen):
             tb = self.tables[step - 1]
-            hip.check(hip.lib.qtts_embedding_gather(hip.ptr(tb), hip.ptr(self.burst_tokens) + 8 * (step - 1) * bs,
-                                                    hip.ptr(self.e_buf), Ht, bs, Ht, tb.shape[0], stream()),
-                      "embedding_gather")
-            x = self._project(bs)
-            self.decoder.forward(x, st.d("positions")[off:off + bs], st.d("slots")[off:off + bs],
-                                 st.d("ctx")[off:off + bs], tables, step + 2, row_seq=None, out=self.h_buf[:bs])
-            hip.linear(self.h_buf[:bs], self.heads[step], self.vocab, out=self.logits[:bs])
+            prev = hip.ptr(self.burst_tokens) + 8 * (step - 1) * bs
+            if self.proj_w is not None:
+                # codec_embedding[step-1](token) -> small_to_mtp_projection in one launch (gathered GEMM rows)
+                hip.check(hip.lib.qtts_linear_fused(hip.ptr(tb), Ht, prev, tb.shape[0], hip.ptr(self.proj_w),
+                                                    hip.ptr(self.proj_b), None, 0, None, 0.0, None, 0, 0,
+                                                    hip.ptr(self.x_buf), h, bs, h, Ht, stream()), "gather+proj")
+                x = self.x_buf[:bs]
+            else:
+                hip.check(hip.lib.qtts_embedding_gather(hip.ptr(tb), prev, hip.ptr(self.e_buf), Ht, bs, Ht,
+                                                        tb.shape[0], stream()), "embedding_gather")
+                x = self.e_buf[:bs]
+            self.decoder.forward_logits(x, st.d("positions")[off:off + bs], st.d("slots")[off:off + bs],
+                                        st.d("ctx")[off:off + bs], tables, step + 2, self.heads[step], self.vocab,
+                                        hidden_out=self.h_buf[:bs], logits_out=self.logits[:bs])
             pick(step)
             off += bs
 

@@ -61,10 +61,9 @@ class TalkerModeModelRunner(ModelRunner):
     def _decode_body(self, bs: int):
         st = self.dstage
         mb = self.max_blocks_per_seq
-        self.decoder.forward(self.x_buf[:bs], st.d("positions")[:bs], st.d("slots")[:bs], st.d("ctx")[:bs],
-                             st.d("tables")[:bs * mb].view(bs, mb), self.config.max_model_len, row_seq=None,
-                             out=self.h_buf[:bs])
-        hip.linear(self.h_buf[:bs], self.codec_head, self.vocab, out=self.logits[:bs])
+        self.decoder.forward_logits(self.x_buf[:bs], st.d("positions")[:bs], st.d("slots")[:bs], st.d("ctx")[:bs],
+                                    st.d("tables")[:bs * mb].view(bs, mb), self.config.max_model_len, self.codec_head,
+                                    self.vocab, hidden_out=self.h_buf[:bs], logits_out=self.logits[:bs])
         hip.check(hip.lib.qtts_argmax(hip.ptr(self.logits), self.vocab, hip.ptr(self.tokens), bs, self.vocab,
                                       hip.stream()), "argmax")
 

@@ -30,6 +30,10 @@ _SIGS = {
     "qtts_pack_weight": (_i, [_p, _p, _i, _i, _p]),
     "qtts_pack_gate_up": (_i, [_p, _p, _p, _i, _i, _p]),
     "qtts_linear": (_i, [_p, _i, _p, _p, _p, _i, _p, _f, _p, _i, _i, _i, _i, _p]),
+    "qtts_linear_fused": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _f, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "qtts_attention_decode_fused": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _f, _p, _i, _i,
+                                         _i, _i, _p, _p]),
+    "qtts_model_forward_logits": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "qtts_linear_swiglu": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _p]),
     "qtts_rmsnorm": (_i, [_p, _i, _p, _f, _p, _i, _i, _i, _p]),
     "qtts_qknorm_rope_store": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
@@ -108,6 +112,26 @@ def linear(x, w_packed, N, bias=None, residual=None, norm_w=None, eps=1e-6, out=
     check(lib.qtts_linear(ptr(x), x.stride(0), ptr(w_packed), ptr(bias), ptr(residual),
                           residual.stride(0) if residual is not None else 0, ptr(norm_w), eps,
                           ptr(out), out.stride(0), M, N, K, stream()), "linear")
+    return out
+
+
+def linear_fused(x, w_packed, N, K=None, gather_ids=None, bias=None, residual=None, norm_w=None, eps=1e-6,
+                 xnorm_out=None, swiglu_input=False, out=None, M=None):
+    """qtts_linear_fused; with gather_ids, x is the table and M = len(gather_ids)."""
+    if gather_ids is not None:
+        M = gather_ids.shape[0] if M is None else M
+        rows = x.shape[0]
+        K = x.shape[1] if K is None else K
+    else:
+        M = x.shape[0] if M is None else M
+        rows = 0
+        K = (x.shape[1] // 2 if swiglu_input else x.shape[1]) if K is None else K
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    check(lib.qtts_linear_fused(ptr(x), x.stride(0), ptr(gather_ids), rows, ptr(w_packed), ptr(bias), ptr(residual),
+                                residual.stride(0) if residual is not None else 0, ptr(norm_w), eps, ptr(xnorm_out),
+                                xnorm_out.stride(0) if xnorm_out is not None else 0, 1 if swiglu_input else 0,
+                                ptr(out), out.stride(0), M, N, K, stream()), "linear_fused")
     return out
 
 

@@ -70,14 +70,16 @@ class HipDecoder:
                               weights[p + "self_attn.v_proj.weight"]], 0)
             wqkv_p = hip.pack_weight(dev(wqkv))
             wo_p = hip.pack_weight(dev(weights[p + "self_attn.o_proj.weight"]))
-            wgu_p = hip.pack_gate_up(dev(weights[p + "mlp.gate_proj.weight"]), dev(weights[p + "mlp.up_proj.weight"]))
+            wgu = torch.cat([weights[p + "mlp.gate_proj.weight"], weights[p + "mlp.up_proj.weight"]], 0)
+            wgu_p = hip.pack_weight(dev(wgu))
             wd_p = hip.pack_weight(dev(weights[p + "mlp.down_proj.weight"]))
             torch.cuda.synchronize()
-            del self._keep[-5:]          # row-major copies are no longer needed once packed
+            del self._keep[-4:]          # row-major copies are no longer needed once packed
             tensors = [dev(weights[p + "input_layernorm.weight"]), wqkv_p, dev(weights[p + "self_attn.q_norm.weight"]),
                        dev(weights[p + "self_attn.k_norm.weight"]), wo_p, dev(weights[p + "post_attention_layernorm.weight"]),
                        wgu_p, wd_p]
             self._keep += [wqkv_p, wo_p, wgu_p, wd_p]
+            self.packed_gate_up = getattr(self, "packed_gate_up", []) + [wgu_p]
             hip.check(hip.lib.qtts_model_set_layer(h, i, *[hip.ptr(t) for t in tensors]), "model_set_layer")
         self.final_norm = dev(weights[prefix + "norm.weight"])
         hip.check(hip.lib.qtts_model_set_final_norm(h, hip.ptr(self.final_norm)), "set_final_norm")
@@ -93,8 +95,16 @@ class HipDecoder:
         hip.check(hip.lib.qtts_model_set_workspace(h, hip.ptr(self.workspace), nbytes, max_rows, max_context),
                   "set_workspace")
 
-    def weight_bytes(self) -> int:
-        return sum(t.numel() * t.element_size() for t in self._keep if t.dim() == 1 and t.numel() > 4096)
+    def forward_logits(self, x, positions, slot_mapping, context_lens, block_tables, max_context, head_packed, vocab,
+                       hidden_out, logits_out, row_seq=None):
+        """Layers + final norm + output head in one C call; writes hidden_out [N,hidden], logits_out [N,vocab]."""
+        N = x.shape[0]
+        assert x.dtype == torch.bfloat16 and x.is_contiguous() and block_tables.is_contiguous()
+        hip.check(hip.lib.qtts_model_forward_logits(self._h, hip.ptr(x), hip.ptr(positions), hip.ptr(slot_mapping),
+                                                    hip.ptr(row_seq), hip.ptr(context_lens), hip.ptr(block_tables),
+                                                    block_tables.shape[1], max_context, N, hip.ptr(hidden_out),
+                                                    hip.ptr(head_packed), vocab, hip.ptr(logits_out), hip.stream()),
+                  "model_forward_logits")
 
     def forward(self, x, positions, slot_mapping, context_lens, block_tables, max_context, row_seq=None, out=None):
         """x [N,hidden] bf16; returns post-final-norm hidden [N,hidden]."""

@@ -249,3 +249,84 @@ def test_embedding_gather(hip):
     ids = torch.tensor([0, 299, 5, 5], dtype=torch.int64)
     got = hip.embedding_gather(table.to(DEV), ids.to(DEV)).cpu()
     assert torch.equal(got, table[ids])
+
+
+def test_linear_fused_variants(hip):
+    """The decoder stack's GEMM: gathered rows + bias, RMSNorm prologue with the normalised rows written
+    out, SwiGLU applied on the way in, residual epilogue — each against the oracle's op sequence."""
+    g = torch.Generator().manual_seed(77)
+    M, H, I, V = 8, 1024, 3072, 512
+    table = torch.randn(V, H, generator=g).bfloat16()
+    ids = torch.tensor([3, 500, 0, 511, 7, 7, 100, 42], dtype=torch.int64)
+    w = (torch.randn(256, H, generator=g) * 0.05).bfloat16()
+    b = torch.randn(256, generator=g).bfloat16()
+    wp = hip.pack_weight(w.to(DEV))
+    got = hip.linear_fused(table.to(DEV), wp, 256, gather_ids=ids.to(DEV), bias=b.to(DEV))
+    assert_bf16_close(got, torch.nn.functional.linear(table[ids], w, b), what="gather+bias")
+
+    x = torch.randn(M, H, generator=g).bfloat16()
+    nw = (1 + 0.1 * torch.randn(H, generator=g)).bfloat16()
+    xn_want = O.rms_norm(x, nw, 1e-6)
+    xn = torch.zeros(M, H, dtype=torch.bfloat16, device=DEV)
+    got = hip.linear_fused(x.to(DEV), wp, 256, norm_w=nw.to(DEV), xnorm_out=xn)
+    assert_bf16_close(xn, xn_want, max_frac=0.005, what="xnorm_out")
+    assert_bf16_close(got, torch.nn.functional.linear(xn_want, w), what="norm+linear")
+
+    wg = (torch.randn(I, H, generator=g) * 0.05).bfloat16()
+    wu = (torch.randn(I, H, generator=g) * 0.05).bfloat16()
+    wd = (torch.randn(H, I, generator=g) * 0.03).bfloat16()
+    gu = hip.linear_fused(x.to(DEV), hip.pack_weight(torch.cat([wg, wu], 0).to(DEV)), 2 * I, norm_w=nw.to(DEV))
+    gu_want = torch.cat([torch.nn.functional.linear(xn_want, wg), torch.nn.functional.linear(xn_want, wu)], 1)
+    assert_bf16_close(gu, gu_want, what="gate|up")
+    # feed the oracle's own gate|up so that only the fused activation + down GEMM + residual are compared
+    got = hip.linear_fused(gu_want.to(DEV), hip.pack_weight(wd.to(DEV)), H, swiglu_input=True, residual=x.to(DEV))
+    act = O.silu_mul(gu_want[:, :I], gu_want[:, I:])
+    assert_bf16_close(got, x + torch.nn.functional.linear(act, wd), what="swiglu-in + down + residual")
+
+
+@pytest.mark.parametrize("Hq,Hkv,ctxs", [(16, 8, [1, 17, 128, 257, 300, 1024, 0, 512]), (4, 2, [3, 260, 0, 511]), (16, 8, [2, 3, 16])])
+def test_attention_decode_fused(hip, Hq, Hkv, ctxs):
+    """q/k norm + RoPE + KV store + attention in one launch == the oracle's separate ops."""
+    g = torch.Generator().manual_seed(sum(ctxs) + 1)
+    B = len(ctxs)
+    nblk = 4 * B + 1
+    kc = torch.randn(nblk, 256, Hkv, 128, generator=g).bfloat16()
+    vc = torch.randn(nblk, 256, Hkv, 128, generator=g).bfloat16()
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * 128, generator=g).bfloat16()
+    qw = (1 + 0.1 * torch.randn(128, generator=g)).bfloat16()
+    kw = (1 + 0.1 * torch.randn(128, generator=g)).bfloat16()
+    perm = torch.randperm(nblk - 1, generator=g) + 1
+    bt = perm[:4 * B].reshape(B, 4).to(torch.int32)
+    cl = torch.tensor(ctxs, dtype=torch.int32)
+    pos = torch.tensor([max(c, 1) for c in ctxs], dtype=torch.int64)           # talker convention: position = len
+    slots = torch.tensor([int(bt[i, (c - 1) // 256]) * 256 + (c - 1) % 256 if c > 0 else -1 for i, c in enumerate(ctxs)],
+                         dtype=torch.int32)
+    # oracle
+    q = qkv[:, :Hq * 128].view(B, Hq, 128)
+    k = qkv[:, Hq * 128:(Hq + Hkv) * 128].view(B, Hkv, 128)
+    v = qkv[:, (Hq + Hkv) * 128:].view(B, Hkv, 128)
+    cos, sin = O.rope_tables(pos, 128, 1000000.0)
+    qo, ko = O.apply_rope(O.rms_norm(q, qw, 1e-6), O.rms_norm(k, kw, 1e-6), cos, sin)
+    kco, vco = kc.clone(), vc.clone()
+    O.store_kvcache(ko, v, kco, vco, slots)
+    want = O.attention_decode(qo, kco, vco, bt, cl, 128 ** -0.5)
+    # HIP
+    from nano_qwen3tts_vllm.models.hip_decoder import rope_tables
+    ct, st = rope_tables(128, 1000000.0, 2048)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    out = torch.empty(B, Hq * 128, dtype=torch.bfloat16, device=DEV)
+    maxc = max(max(ctxs), 1)
+    ws = torch.empty(hip.lib.qtts_attn_workspace_bytes(B, Hq, maxc), dtype=torch.uint8, device=DEV)
+    qkvd, btd, cld = qkv.to(DEV), bt.to(DEV), cl.to(DEV)
+    qwd, kwd, ctd, std, posd, slotsd = qw.to(DEV), kw.to(DEV), ct.to(DEV), st.to(DEV), pos.to(DEV), slots.to(DEV)   # keep alive
+    hip.check(hip.lib.qtts_attention_decode_fused(hip.ptr(qkvd), qkvd.stride(0), hip.ptr(qwd), hip.ptr(kwd),
+                                                  1e-6, hip.ptr(ctd), hip.ptr(std), 2048, hip.ptr(posd),
+                                                  hip.ptr(slotsd), hip.ptr(kcd), hip.ptr(vcd), hip.ptr(btd), 4,
+                                                  hip.ptr(cld), maxc, 128 ** -0.5, hip.ptr(out), Hq * 128, B, Hq, Hkv,
+                                                  hip.ptr(ws), hip.stream()), "attention_decode_fused")
+    torch.cuda.synchronize()
+    assert torch.allclose(out.float().cpu().view(B, Hq, 128), want.float(), atol=1e-2, rtol=2e-2)
+    # the cache received exactly the oracle's new K/V rows (K up to 1-ulp norm differences) and nothing else changed
+    kdiff = (kcd.cpu().float() - kco.float()).abs()
+    assert float(kdiff.max()) <= 0.0625 and float((kdiff > 0).float().mean()) < 1e-4
+    assert torch.equal(vcd.cpu(), vco)
