@@ -83,6 +83,10 @@ int qtts_linear_fused(const void *x, int ldx, const int64_t *gather_ids, int gat
                       const void *norm_w, float eps, void *xnorm_out, int ldxn, int swiglu_input,
                       void *out, int ldo, int M, int N, int K, qtts_stream_t stream);
 
+/* qtts_linear_swiglu on the decoder stack's tile-loop kernel (weights from qtts_pack_gate_up). */
+int qtts_linear_swiglu_fused(const void *x, int ldx, const void *w_gate_up_packed, const void *norm_w,
+                             float eps, void *out, int ldo, int M, int I, int K, qtts_stream_t stream);
+
 /* y = rmsnorm(x) * w  (P/layers/layernorm.py:17-27).  x,y [M,H]. */
 int qtts_rmsnorm(const void *x, int ldx, const void *w, float eps, void *y, int ldy,
                  int M, int H, qtts_stream_t stream);
@@ -188,7 +192,7 @@ qtts_model_t *qtts_model_create(int hidden, int n_layers, int n_heads, int n_kv_
                                 int head_dim, int intermediate, float rms_eps);
 void qtts_model_destroy(qtts_model_t *m);
 /* wqkv_packed = qtts_pack_weight of [q_proj; k_proj; v_proj] rows, w_gate_up_packed =
- * qtts_pack_weight of [gate_proj; up_proj] rows (plain concatenation). */
+ * qtts_pack_gate_up(gate_proj, up_proj). */
 int qtts_model_set_layer(qtts_model_t *m, int layer, const void *input_norm_w,
                          const void *wqkv_packed, const void *q_norm_w, const void *k_norm_w,
                          const void *wo_packed, const void *post_norm_w,

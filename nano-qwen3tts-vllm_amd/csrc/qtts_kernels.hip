@@ -47,6 +47,20 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 }
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }   // round through bf16
 
+// Cross-lane sums inside a 16-lane row on the DPP path (no LDS crossbar round trip).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v);      // quad_perm [1,0,3,2]   (lane ^ 1)
+    v += dpp_f32<0x4E>(v);      // quad_perm [2,3,0,1]   (lane ^ 2)
+    v += dpp_f32<0x141>(v);     // row_half_mirror: the other quad of the 8-lane half
+    v += dpp_f32<0x140>(v);     // row_mirror: the other half of the 16-lane row
+    return v;
+}
+__device__ __forceinline__ float row16_xor8(float v) { return dpp_f32<0x128>(v); }   // row_ror:8 == lane ^ 8
+
 union Frag {
     uint4 u;
     u32x4_t n;
@@ -340,7 +354,9 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
     return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
 }
 
-template <int KSW, int PRO, bool DB>
+// EPI: 0 = bias/residual epilogue; 1 = SwiGLU pair: even tiles are gate rows, odd tiles the up rows of the same
+// 16 outputs (qtts_pack_gate_up order), out[m][16*(t/2)..] = bf16(bf16(silu(bf16 gate)) * bf16 up).
+template <int KSW, int PRO, bool DB, int EPI>
 __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
     extern __shared__ float4_t smem4[];
     const int lane = threadIdx.x & 63;
@@ -398,6 +414,9 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
     }
     float *normred = reinterpret_cast<float *>(smem4 + (size_t)2 * NW * 64);
     if (PRO == 1) {
+        uint4 nwv[KSW];                                  // requested before the barrier so both L2 trips overlap
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) nwv[i] = *reinterpret_cast<const uint4 *>(p.nw + 32 * (ks0 + i) + 8 * g);
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < KSW; ++i) {
@@ -420,7 +439,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
 #pragma unroll
         for (int i = 0; i < KSW; ++i) {
             const int k = 32 * (ks0 + i) + 8 * g;
-            const uint4 wv = *reinterpret_cast<const uint4 *>(p.nw + k);
+            const uint4 wv = nwv[i];
             const uint32_t x4[4] = {xb[i].u.x, xb[i].u.y, xb[i].u.z, xb[i].u.w}, w4[4] = {wv.x, wv.y, wv.z, wv.w};
             uint32_t o4[4];
 #pragma unroll
@@ -437,6 +456,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
     }
 
     // ---- tile loop
+    float4_t gate_sum = {0.f, 0.f, 0.f, 0.f};
     auto tile_body = [&](const int cur, const int t, const int it) {
         if (DB && t + 1 < t_end) {
             const uint4 *wptr = p.wp + ((size_t)(t + 1) * KS + ks0) * 64 + lane;
@@ -454,6 +474,22 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
         if (wave == 0) {
             float4_t sum = red[lane];
             for (int w = 1; w < NW; ++w) sum += red[w * 64 + lane];
+            if (EPI == 1) {
+                if ((t & 1) == 0) {
+                    gate_sum = sum;
+                } else if (mvalid) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float gv = rbf(gate_sum[j]);
+                        const float sv = rbf(gv / (1.0f + expf(-gv)));
+                        v[j] = sv * rbf(sum[j]);
+                    }
+                    *reinterpret_cast<uint2 *>(p.out + (size_t)m * p.ldo + 16 * (t >> 1) + 4 * g) =
+                        make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                }
+                return;
+            }
             const int n = 16 * t + 4 * g;
             if (mvalid) {
                 uint32_t o2[2];
@@ -479,19 +515,20 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
     }
 }
 
-template <int KSW, int PRO, bool DB>
+template <int KSW, int PRO, bool DB, int EPI>
 static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs &a) {
     size_t shmem = (size_t)2 * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
-    hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB>), grid, dim3(NW * 64), shmem, s, a);
+    hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI>), grid, dim3(NW * 64), shmem, s, a);
 }
 
-static int launch_linear2(LinArgs a, int pro, hipStream_t s) {
+static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = false) {
     QCHECK(a.x && a.wp && a.out, "linear: null pointer");
     QCHECK(a.M > 0 && a.N > 0 && a.K > 0, "linear: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
     QCHECK(a.N % 16 == 0 && a.K % 32 == 0, "linear: need N%%16==0 and K%%32==0 (N=%d K=%d)", a.N, a.K);
     QCHECK(a.ldx % 8 == 0 && a.ldx >= (pro == 2 ? 2 * a.K : a.K), "linear: x row stride %d too small or not a multiple of 8", a.ldx);
-    QCHECK(a.ldo % 4 == 0 && a.ldo >= a.N, "linear: bad out row stride %d", a.ldo);
+    QCHECK(a.ldo % 4 == 0 && a.ldo >= (silu_pairs ? a.N / 2 : a.N), "linear: bad out row stride %d", a.ldo);
     QCHECK(!a.res || a.ldr >= a.N, "linear: residual row stride %d < N", a.ldr);
+    QCHECK(!silu_pairs || (a.N % 32 == 0 && !a.bias && !a.res && pro != 2), "linear: bad SwiGLU-pair arguments");
     QCHECK(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.wp & 15) == 0 && ((uintptr_t)a.out & 7) == 0, "linear: misaligned pointer");
     QCHECK(pro != 1 || a.nw, "linear: norm prologue without weight");
     QCHECK(!a.xnorm_out || (a.ldxn % 8 == 0 && a.ldxn >= a.K), "linear: bad xnorm_out stride");
@@ -509,15 +546,21 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s) {
     const bool db = KSW <= 12;
     int tpw = 1;
     if (db) {
-        const int target = g_tune_t > 0 ? g_tune_t * 256 : 256;
+        const int target = g_tune_t > 0 ? g_tune_t * 128 : 256;
         tpw = (ntiles + target - 1) / target;
+    }
+    if (silu_pairs) {
+        QCHECK(db, "linear: SwiGLU pairs need the double-buffered kernel (K=%d)", a.K);
+        tpw = (tpw + 1) & ~1;                       // whole gate/up pairs per workgroup
     }
     a.tiles_per_wg = tpw;
     dim3 grid((ntiles + tpw - 1) / tpw, (a.M + 15) / 16);
 #define QL2(KSW_, DB_) case KSW_: \
-        if (pro == 0) launch_linear2_inst<KSW_, 0, DB_>(grid, NW, s, a); \
-        else if (pro == 1) launch_linear2_inst<KSW_, 1, DB_>(grid, NW, s, a); \
-        else launch_linear2_inst<KSW_, 2, DB_>(grid, NW, s, a); \
+        if (silu_pairs && DB_) { if (pro == 1) launch_linear2_inst<KSW_, 1, DB_, DB_ ? 1 : 0>(grid, NW, s, a); \
+                                 else launch_linear2_inst<KSW_, 0, DB_, DB_ ? 1 : 0>(grid, NW, s, a); } \
+        else if (pro == 0) launch_linear2_inst<KSW_, 0, DB_, 0>(grid, NW, s, a); \
+        else if (pro == 1) launch_linear2_inst<KSW_, 1, DB_, 0>(grid, NW, s, a); \
+        else launch_linear2_inst<KSW_, 2, DB_, 0>(grid, NW, s, a); \
         break;
     switch (KSW) {
         QL2(1, true) QL2(2, true) QL2(4, true) QL2(6, true) QL2(8, true) QL2(12, true) QL2(24, false)
@@ -540,6 +583,16 @@ extern "C" int qtts_linear_fused(const void *x, int ldx, const int64_t *gather_i
     a.nw = (const bf16_t *)norm_w; a.eps = eps; a.xnorm_out = (bf16_t *)xnorm_out; a.ldxn = ldxn;
     a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.tiles_per_wg = 1;
     return launch_linear2(a, swiglu_input ? 2 : (norm_w ? 1 : 0), (hipStream_t)stream);
+}
+
+extern "C" int qtts_linear_swiglu_fused(const void *x, int ldx, const void *w_gate_up_packed, const void *norm_w,
+                                        float eps, void *out, int ldo, int M, int I, int K, qtts_stream_t stream) {
+    LinArgs a;
+    a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0;
+    a.wp = (const uint4 *)w_gate_up_packed; a.bias = nullptr; a.res = nullptr; a.ldr = 0;
+    a.nw = (const bf16_t *)norm_w; a.eps = eps; a.xnorm_out = nullptr; a.ldxn = 0;
+    a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = 2 * I; a.K = K; a.tiles_per_wg = 2;
+    return launch_linear2(a, norm_w ? 1 : 0, (hipStream_t)stream, true);
 }
 
 // ------------------------------------------------------------------ rmsnorm (stand-alone)
@@ -735,11 +788,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += qf[h][j] * kf[j];
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 4);
-            s += __shfl_xor(s, 8);
-            s *= scale;
+            s = row16_sum(s) * scale;
             if (valid) {
                 const float mn = fmaxf(mx[h], s);
                 const float corr = __expf(mx[h] - mn);
@@ -880,10 +929,7 @@ __device__ __forceinline__ void norm_rope8(const float (&x)[8], const bf16_t *__
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
-    ss += __shfl_xor(ss, 1);
-    ss += __shfl_xor(ss, 2);
-    ss += __shfl_xor(ss, 4);
-    ss += __shfl_xor(ss, 8);
+    ss = row16_sum(ss);
     const float rstd = 1.0f / sqrtf(ss / 128.0f + eps);
     const int d0 = 8 * l16;
     const bool hi = l16 >= 8;                         // dims 64..127
@@ -894,7 +940,7 @@ __device__ __forceinline__ void norm_rope8(const float (&x)[8], const bf16_t *__
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float n = rbf(rbf(x[j] * rstd) * bf2f(wv.h[j]));
-        const float partner = __shfl_xor(n, 8);       // the element 64 dims away
+        const float partner = row16_xor8(n);          // the element 64 dims away
         const float c = bf2f(cv.h[j]), sn = bf2f(sv.h[j]);
         o[j] = rbf(rbf(n * c) + rbf((hi ? partner : -partner) * sn));
     }
@@ -989,6 +1035,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnFusedA
         if (pass == 1) issue_loads(base);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+            if (base + i * 16 >= ctx) break;          // uniform: no token left in this or later rounds
             const int t = base + i * 16 + grp;
             const bool valid = t < ctx;
             const bool is_new = t == ctx - 1;
@@ -1003,11 +1050,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnFusedA
                 float s = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += qf[h][j] * kf[j];
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 4);
-                s += __shfl_xor(s, 8);
-                s *= p.scale;
+                s = row16_sum(s) * p.scale;
                 if (valid) {
                     const float mn = fmaxf(mx[h], s);
                     const float corr = __expf(mx[h] - mn);
@@ -1471,7 +1514,7 @@ static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
     const size_t qkvw = (size_t)(m->n_heads + 2 * m->n_kv_heads) * 128;
     L.qkv = off; off += align256((size_t)rows * qkvw * 2);
     L.attn = off; off += align256((size_t)rows * m->n_heads * 128 * 2);
-    L.act = off; off += align256((size_t)rows * 2 * m->inter * 2);
+    L.act = off; off += align256((size_t)rows * m->inter * 2);
     L.xa = off; off += align256((size_t)rows * m->hidden * 2);
     L.xb = off; off += align256((size_t)rows * m->hidden * 2);
     L.att_ws = off; off += align256(qtts_attn_workspace_bytes(rows, m->n_heads, max_context));
@@ -1541,10 +1584,8 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         }
         if ((rc = qtts_linear_fused(attn, Hq * 128, nullptr, 0, L.wo, nullptr, cur, H, nullptr, 0.f, nullptr, 0, 0, xa, H,
                                     N, H, Hq * 128, stream))) return rc;
-        // gate|up columns side by side; the SwiGLU is applied by the down projection's prologue
-        if ((rc = qtts_linear_fused(xa, H, nullptr, 0, L.wgu, nullptr, nullptr, 0, L.post_norm, m->eps, nullptr, 0, 0, act,
-                                    2 * m->inter, N, 2 * m->inter, H, stream))) return rc;
-        if ((rc = qtts_linear_fused(act, 2 * m->inter, nullptr, 0, L.wdown, nullptr, xa, H, nullptr, 0.f, nullptr, 0, 1,
+        if ((rc = qtts_linear_swiglu_fused(xa, H, L.wgu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
+        if ((rc = qtts_linear_fused(act, m->inter, nullptr, 0, L.wdown, nullptr, xa, H, nullptr, 0.f, nullptr, 0, 0,
                                     xb, H, N, H, m->inter, stream))) return rc;
         // Fixed roles: xa = post-attention residual stream, xb = layer output.  The next layer reads xb
         // (qkv GEMM, o_proj residual) before its down_proj overwrites it, all stream-ordered.

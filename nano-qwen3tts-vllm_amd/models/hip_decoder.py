@@ -70,11 +70,10 @@ class HipDecoder:
                               weights[p + "self_attn.v_proj.weight"]], 0)
             wqkv_p = hip.pack_weight(dev(wqkv))
             wo_p = hip.pack_weight(dev(weights[p + "self_attn.o_proj.weight"]))
-            wgu = torch.cat([weights[p + "mlp.gate_proj.weight"], weights[p + "mlp.up_proj.weight"]], 0)
-            wgu_p = hip.pack_weight(dev(wgu))
+            wgu_p = hip.pack_gate_up(dev(weights[p + "mlp.gate_proj.weight"]), dev(weights[p + "mlp.up_proj.weight"]))
             wd_p = hip.pack_weight(dev(weights[p + "mlp.down_proj.weight"]))
             torch.cuda.synchronize()
-            del self._keep[-4:]          # row-major copies are no longer needed once packed
+            del self._keep[-5:]          # row-major copies are no longer needed once packed
             tensors = [dev(weights[p + "input_layernorm.weight"]), wqkv_p, dev(weights[p + "self_attn.q_norm.weight"]),
                        dev(weights[p + "self_attn.k_norm.weight"]), wo_p, dev(weights[p + "post_attention_layernorm.weight"]),
                        wgu_p, wd_p]

@@ -79,12 +79,13 @@ def test_linear_swiglu(hip, M, I, K):
     h = O.rms_norm(x, nw, 1e-6)
     want = O.silu_mul(torch.nn.functional.linear(h, wg), torch.nn.functional.linear(h, wu))
     wp = hip.pack_gate_up(wg.to(DEV), wu.to(DEV))
-    got = hip.linear_swiglu(x.to(DEV), wp, I, norm_w=nw.to(DEV), eps=1e-6)
-    # two chained roundings: a 1-ulp flip of gate or up moves the product by up to 2 ulp
-    got, want = got.float().cpu(), want.float()
-    diff = (got - want).abs()
-    assert float((diff > want.abs() * 2.0 ** -6 + 1e-6).float().mean()) == 0.0
-    assert float((diff > 0).float().mean()) < 0.03
+    want = want.float()
+    for fn in (hip.linear_swiglu, hip.linear_swiglu_fused):
+        got = fn(x.to(DEV), wp, I, norm_w=nw.to(DEV), eps=1e-6).float().cpu()
+        # two chained roundings: a 1-ulp flip of gate or up moves the product by up to 2 ulp
+        diff = (got - want).abs()
+        assert float((diff > want.abs() * 2.0 ** -6 + 1e-6).float().mean()) == 0.0
+        assert float((diff > 0).float().mean()) < 0.03
 
 
 def test_linear_rejects_bad_shapes(hip):

@@ -94,6 +94,50 @@ def linear():
         print(line, flush=True)
 
 
+def linear2():
+    """v1 (one tile set per workgroup) against v2 (tile loop, double buffer) per decoder shape, graph-timed."""
+    B = 8
+    shapes = [("qkv 1.7B", 4096, 2048, "norm"), ("o 1.7B", 2048, 2048, "res"), ("gate|up 1.7B", 12288, 2048, "silu"),
+              ("down 1.7B", 2048, 6144, "res"), ("qkv pred", 4096, 1024, "norm"), ("o pred", 1024, 2048, "res"),
+              ("gate|up pred", 6144, 1024, "silu"), ("down pred", 1024, 3072, "res"), ("head talker", 3072, 2048, "norm"),
+              ("head pred", 2048, 1024, "norm")]
+    for name, N, K, kind in shapes:
+        nbuf = max(2, int(600e6 // (N * K * 2)))
+        ws = [torch.randn(N * K, device=dev).bfloat16() * 0.02 for _ in range(nbuf)]
+        x = torch.randn(B, 2 * K if kind == "swiglu" else K, device=dev).bfloat16()
+        nw = torch.ones(K, device=dev).bfloat16()
+        out = torch.empty(B, N, dtype=torch.bfloat16, device=dev)
+        res = torch.randn(B, N, device=dev).bfloat16()
+        line = f"{name:14s} N={N:5d} K={K:5d} {N*K*2/1e6:6.1f} MB:"
+
+        def v1():
+            for w in ws:
+                if kind == "silu":
+                    hip.linear_swiglu(x, w, N // 2, norm_w=nw, out=out[:, :N // 2])
+                    continue
+                hip.linear(x[:, :K], w, N, norm_w=nw if kind == "norm" else None, residual=res if kind != "norm" else None, out=out)
+
+        def v2():
+            for w in ws:
+                if kind == "silu":
+                    hip.linear_swiglu_fused(x, w, N // 2, norm_w=nw, out=out[:, :N // 2])
+                else:
+                    hip.linear_fused(x, w, N, K=K, norm_w=nw if kind == "norm" else None, residual=res if kind != "norm" else None,
+                                     swiglu_input=(kind == "swiglu"), out=out)
+
+        for label, fn, tunes in (("v1", v1, [(0, 0)]), ("v2", v2, [(0, 0), (0, 2), (0, 3)])):
+            for ksw, t in tunes:
+                hip.lib.qtts_tune_linear(ksw, t)
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    fn()
+                    gr = hip.Graph.capture(fn)
+                us = timed(lambda: gr.launch(), nbuf)
+                line += f"  {label}/t{t}: {us:5.1f}us {N*K*2/us/1e6:5.2f}TB/s"
+        hip.lib.qtts_tune_linear(0, 0)
+        print(line, flush=True)
+
+
 def frame():
     import json, tempfile
     sys.path.insert(0, ROOT)
@@ -133,4 +177,4 @@ def frame():
 
 
 if __name__ == "__main__":
-    {"launch": launch, "linear": linear, "frame": frame}[sys.argv[1]]()
+    {"launch": launch, "linear": linear, "linear2": linear2, "frame": frame}[sys.argv[1]]()
