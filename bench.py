@@ -208,7 +208,7 @@ def main():
             "frame_roofline": {"bound": "hbm", "bytes_per_frame": bytes_frame,
                                "achieved": bytes_frame / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                "unit": "GB/s", "frac": bytes_frame / (ms_per_step * 1e-3) / HBM_PEAK},
-            "roofline": {"bound": "hbm", "kernel": "linear_kernel<8,2,SILU,NORM> (talker RMSNorm+gate/up GEMM+SwiGLU)",
+            "roofline": {"bound": "hbm", "kernel": "linear2_kernel<8,1,true,1> (talker RMSNorm + gate/up GEMM + SwiGLU launch)",
                          "achieved": kbytes / ksec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": kbytes / ksec / HBM_PEAK, "traffic": None, "bytes_per_launch": kbytes,
                          "us_per_launch": ksec * 1e6},

@@ -41,8 +41,9 @@ const char *qtts_last_error(void);
  * into MFMA fragment order so that one wave-instruction reads 1 KiB contiguous:
  *   packed[nt][ks][lane][j] = W[16*nt + (lane&15)][32*ks + 8*(lane>>4) + j]
  * nt < N/16, ks < K/32, lane < 64, j < 8.  Requires N % 16 == 0, K % 32 == 0.
- * `gate_up` interleaves two [I,K] matrices tile-wise (tile 2t = gate rows
- * 16t.., tile 2t+1 = up rows 16t..) for the fused SwiGLU epilogue. */
+ * `gate_up` interleaves two [I,K] matrices so that tile t holds gate rows 8t..8t+7 in its
+ * rows 0..7 and up rows 8t..8t+7 in rows 8..15 (I % 8 == 0): every MFMA tile then carries
+ * both operands of 8 SwiGLU outputs. */
 size_t qtts_packed_weight_bytes(int N, int K);
 int qtts_pack_weight(const void *w_rowmajor, void *packed, int N, int K, qtts_stream_t stream);
 int qtts_pack_gate_up(const void *gate, const void *up, void *packed, int I, int K, qtts_stream_t stream);
@@ -82,10 +83,6 @@ int qtts_linear_fused(const void *x, int ldx, const int64_t *gather_ids, int gat
                       const void *w_packed, const void *bias, const void *residual, int ldr,
                       const void *norm_w, float eps, void *xnorm_out, int ldxn, int swiglu_input,
                       void *out, int ldo, int M, int N, int K, qtts_stream_t stream);
-
-/* qtts_linear_swiglu on the decoder stack's tile-loop kernel (weights from qtts_pack_gate_up). */
-int qtts_linear_swiglu_fused(const void *x, int ldx, const void *w_gate_up_packed, const void *norm_w,
-                             float eps, void *out, int ldo, int M, int I, int K, qtts_stream_t stream);
 
 /* y = rmsnorm(x) * w  (P/layers/layernorm.py:17-27).  x,y [M,H]. */
 int qtts_rmsnorm(const void *x, int ldx, const void *w, float eps, void *y, int ldy,

@@ -98,236 +98,39 @@ extern "C" int qtts_pack_weight(const void *w, void *packed, int N, int K, qtts_
     return QTTS_OK;
 }
 
-extern "C" int qtts_pack_gate_up(const void *gate, const void *up, void *packed, int I, int K, qtts_stream_t stream) {
-    QCHECK(gate && up && packed, "pack_gate_up: null pointer");
-    QCHECK(I > 0 && K > 0 && I % 16 == 0 && K % 32 == 0, "pack_gate_up: need I%%16==0, K%%32==0 (I=%d K=%d)", I, K);
-    long total = (long)(I / 16) * (K / 32) * 64;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t *)gate, (uint4 *)packed, I, K, 2, 0);
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t *)up, (uint4 *)packed, I, K, 2, 1);
-    QLAUNCH();
-    return QTTS_OK;
+// Tile t of the packed gate/up matrix holds gate rows 8t..8t+7 in its rows 0..7 and up rows 8t..8t+7 in
+// its rows 8..15, so that every 16-row MFMA tile carries both operands of 8 SwiGLU outputs.
+__global__ void pack_gate_up_kernel(const bf16_t *__restrict__ gate, const bf16_t *__restrict__ up,
+                                    uint4 *__restrict__ packed, int I, int K) {
+    const int KS = K >> 5;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)(I >> 3) * KS * 64;
+    if (idx >= total) return;
+    int lane = idx & 63;
+    long f = idx >> 6;
+    int ks = f % KS;
+    int t = f / KS;
+    int r = lane & 15, g = lane >> 4;
+    const bf16_t *src = (r < 8 ? gate : up) + (size_t)(8 * t + (r & 7)) * K + 32 * ks + 8 * g;
+    packed[((size_t)t * KS + ks) * 64 + lane] = *reinterpret_cast<const uint4 *>(src);
 }
 
-// ------------------------------------------------------------------ linear (skinny GEMM, MFMA)
-// Workgroup: NW waves; wave w owns k-steps [w*KSW, (w+1)*KSW) of T consecutive
-// 16-row weight tiles; blockIdx.y selects the 16-token row tile.
-// Variants that keep extra fragments live (fused norm, SwiGLU pair, T == 2) are
-// limited to 8 waves so that they get the 256-VGPR budget.
-template <int KSW, int T, bool SILU, bool NORM>
-__global__ __launch_bounds__((SILU || NORM || T == 2) ? 512 : 1024) void linear_kernel(
-    const bf16_t *__restrict__ x, int ldx, const uint4 *__restrict__ wp, const bf16_t *__restrict__ bias,
-    const bf16_t *__restrict__ res, int ldr, const bf16_t *__restrict__ nw, float eps,
-    bf16_t *__restrict__ out, int ldo, int M, int N, int K) {
-    extern __shared__ float4_t smem4[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int NW = blockDim.x >> 6;
-    const int g = lane >> 4, r = lane & 15;
-    const int KS = K >> 5;
-    const int m = blockIdx.y * 16 + r;
-    const bool mvalid = m < M;
-    const int ks0 = wave * KSW;
-    const int nt0 = blockIdx.x * T;
-
-    // Weight fragments of the first tile are requested before anything else so
-    // that the HBM latency overlaps the activation prologue.
-    Frag a[T][KSW];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const uint4 *wptr = wp + ((size_t)(nt0 + t) * KS + ks0) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < KSW; ++i) a[t][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
-    }
-
-    Frag xb[KSW];
-#pragma unroll
-    for (int i = 0; i < KSW; ++i) {
-        if (mvalid)
-            xb[i].u = *reinterpret_cast<const uint4 *>(x + (size_t)m * ldx + 32 * (ks0 + i) + 8 * g);
-        else
-            xb[i].u = make_uint4(0, 0, 0, 0);
-    }
-
-    float *normred = reinterpret_cast<float *>(smem4 + (size_t)T * NW * 64);
-    if (NORM) {
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < KSW; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = bf2f(xb[i].h[j]);
-                ss += v * v;
-            }
-        ss += __shfl_xor(ss, 16);
-        ss += __shfl_xor(ss, 32);
-        if (g == 0) normred[wave * 16 + r] = ss;
-        __syncthreads();
-        float tot = 0.f;
-        for (int w = 0; w < NW; ++w) tot += normred[w * 16 + r];
-        const float rstd = 1.0f / sqrtf(tot / (float)K + eps);
-#pragma unroll
-        for (int i = 0; i < KSW; ++i) {
-            Frag wv;
-            wv.u = *reinterpret_cast<const uint4 *>(nw + 32 * (ks0 + i) + 8 * g);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = rbf(bf2f(xb[i].h[j]) * rstd);
-                xb[i].h[j] = f2bf(v * bf2f(wv.h[j]));
-            }
-        }
-    }
-
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        float4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < KSW; ++i)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][i].v, xb[i].v, acc, 0, 0, 0);
-        smem4[(t * NW + wave) * 64 + lane] = acc;
-    }
-    __syncthreads();
-
-    if (SILU) {
-        // T == 2: tile 0 = gate rows, tile 1 = up rows of the same 16 outputs.
-        if (threadIdx.x < 64) {
-            const int l = threadIdx.x;
-            float4_t ga = {0.f, 0.f, 0.f, 0.f}, ua = {0.f, 0.f, 0.f, 0.f};
-            for (int w = 0; w < NW; ++w) {
-                ga += smem4[(0 * NW + w) * 64 + l];
-                ua += smem4[(1 * NW + w) * 64 + l];
-            }
-            const int mm = blockIdx.y * 16 + (l & 15);
-            const int n = 16 * blockIdx.x + 4 * (l >> 4);
-            if (mm < M) {
-                bf16_t o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float gv = rbf(ga[j]);
-                    float uv = rbf(ua[j]);
-                    float s = rbf(gv / (1.0f + expf(-gv)));
-                    o[j] = f2bf(s * uv);
-                }
-                *reinterpret_cast<uint2 *>(out + (size_t)mm * ldo + n) = *reinterpret_cast<uint2 *>(o);
-            }
-        }
-    } else {
-        for (int e = threadIdx.x; e < 64 * T; e += blockDim.x) {
-            const int t = e >> 6, l = e & 63;
-            float4_t acc = {0.f, 0.f, 0.f, 0.f};
-            for (int w = 0; w < NW; ++w) acc += smem4[(t * NW + w) * 64 + l];
-            const int mm = blockIdx.y * 16 + (l & 15);
-            const int n = 16 * (nt0 + t) + 4 * (l >> 4);
-            if (mm < M) {
-                bf16_t o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[j];
-                    if (bias) v += bf2f(bias[n + j]);
-                    v = rbf(v);
-                    if (res) v = v + bf2f(res[(size_t)mm * ldr + n + j]);
-                    o[j] = f2bf(v);
-                }
-                *reinterpret_cast<uint2 *>(out + (size_t)mm * ldo + n) = *reinterpret_cast<uint2 *>(o);
-            }
-        }
-    }
+extern "C" int qtts_pack_gate_up(const void *gate, const void *up, void *packed, int I, int K, qtts_stream_t stream) {
+    QCHECK(gate && up && packed, "pack_gate_up: null pointer");
+    QCHECK(I > 0 && K > 0 && I % 8 == 0 && K % 32 == 0, "pack_gate_up: need I%%8==0, K%%32==0 (I=%d K=%d)", I, K);
+    long total = (long)(I / 8) * (K / 32) * 64;
+    hipLaunchKernelGGL(pack_gate_up_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t *)gate, (const bf16_t *)up, (uint4 *)packed, I, K);
+    QLAUNCH();
+    return QTTS_OK;
 }
 
 static int g_tune_ksw = 0;   // 0 = automatic
 static int g_tune_t = 0;
 extern "C" void qtts_tune_linear(int ksw, int t) { g_tune_ksw = ksw; g_tune_t = t; }
 
-static int pick_ksw(int KS, int max_nw) {
-    static const int prefs[] = {8, 12, 6, 4, 2, 1};
-    if (g_tune_ksw > 0 && KS % g_tune_ksw == 0 && KS / g_tune_ksw <= max_nw) {
-        for (int p : prefs) if (p == g_tune_ksw) return p;
-    }
-    for (int p : prefs)
-        if (KS % p == 0 && KS / p <= max_nw) return p;
-    return 0;
-}
-
-template <int KSW, int T, bool SILU, bool NORM>
-static void launch_linear_inst(dim3 grid, int NW, hipStream_t s, const bf16_t *x, int ldx, const uint4 *wp,
-                               const bf16_t *bias, const bf16_t *res, int ldr, const bf16_t *nw, float eps,
-                               bf16_t *out, int ldo, int M, int N, int K) {
-    size_t shmem = (size_t)T * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
-    hipLaunchKernelGGL((linear_kernel<KSW, T, SILU, NORM>), grid, dim3(NW * 64), shmem, s, x, ldx, wp, bias, res, ldr,
-                       nw, eps, out, ldo, M, N, K);
-}
-
-template <int KSW>
-static void launch_linear_ksw(int T, bool silu, bool norm, dim3 grid, int NW, hipStream_t s, const bf16_t *x, int ldx,
-                              const uint4 *wp, const bf16_t *bias, const bf16_t *res, int ldr, const bf16_t *nw,
-                              float eps, bf16_t *out, int ldo, int M, int N, int K) {
-#define QL(T_, S_, N_) launch_linear_inst<KSW, T_, S_, N_>(grid, NW, s, x, ldx, wp, bias, res, ldr, nw, eps, out, ldo, M, N, K)
-    if (silu) {
-        if (norm) QL(2, true, true); else QL(2, true, false);
-    } else if (T == 2) {
-        if (norm) QL(2, false, true); else QL(2, false, false);
-    } else {
-        if (norm) QL(1, false, true); else QL(1, false, false);
-    }
-#undef QL
-}
-
-static int launch_linear(bool silu, const void *x, int ldx, const void *wp, const void *bias, const void *res, int ldr,
-                         const void *nw, float eps, void *out, int ldo, int M, int N, int K, hipStream_t s) {
-    // N counts packed weight rows (2*I for the gate/up interleave).
-    QCHECK(x && wp && out, "linear: null pointer");
-    QCHECK(M > 0 && N > 0 && K > 0, "linear: empty shape M=%d N=%d K=%d", M, N, K);
-    QCHECK(N % 16 == 0 && K % 32 == 0, "linear: need N%%16==0 and K%%32==0 (N=%d K=%d)", N, K);
-    QCHECK(ldx % 8 == 0 && ldx >= K, "linear: x row stride %d must be a multiple of 8 and >= K", ldx);
-    QCHECK(ldo % 4 == 0, "linear: out row stride %d must be a multiple of 4", ldo);
-    QCHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)wp & 15) == 0 && ((uintptr_t)out & 7) == 0, "linear: misaligned pointer");
-    const int KS = K / 32;
-    const int ntiles = N / 16;
-    int T = 1;
-    if (silu) {
-        QCHECK(ntiles % 2 == 0, "linear_swiglu: odd tile count");
-        T = 2;
-    } else if (g_tune_t == 2 && ntiles % 2 == 0) {
-        T = 2;
-    }
-    const int max_nw = (silu || nw != nullptr || T == 2) ? 8 : 16;
-    const int KSW = pick_ksw(KS, max_nw);
-    QCHECK(KSW > 0, "linear: K=%d cannot be split over <=%d waves", K, max_nw);
-    const int NW = KS / KSW;
-    dim3 grid(ntiles / T, (M + 15) / 16);
-    const bf16_t *xx = (const bf16_t *)x;
-    const uint4 *ww = (const uint4 *)wp;
-#define QK(KSW_) case KSW_: launch_linear_ksw<KSW_>(T, silu, nw != nullptr, grid, NW, s, xx, ldx, ww, (const bf16_t *)bias, \
-        (const bf16_t *)res, ldr, (const bf16_t *)nw, eps, (bf16_t *)out, ldo, M, N, K); break;
-    switch (KSW) {
-        QK(1) QK(2) QK(4) QK(6) QK(8) QK(12)
-        default: QFAIL(QTTS_EINVAL, "linear: unsupported KSW %d", KSW);
-    }
-#undef QK
-    QLAUNCH();
-    return QTTS_OK;
-}
-
-extern "C" int qtts_linear(const void *x, int ldx, const void *w_packed, const void *bias, const void *residual,
-                           int ldr, const void *norm_w, float eps, void *out, int ldo, int M, int N, int K,
-                           qtts_stream_t stream) {
-    if (residual) QCHECK(ldr >= N, "linear: residual row stride %d < N", ldr);
-    QCHECK(ldo >= N, "linear: out row stride %d < N=%d", ldo, N);
-    return launch_linear(false, x, ldx, w_packed, bias, residual, ldr, norm_w, eps, out, ldo, M, N, K,
-                         (hipStream_t)stream);
-}
-
-extern "C" int qtts_linear_swiglu(const void *x, int ldx, const void *w_gate_up_packed, const void *norm_w, float eps,
-                                  void *out, int ldo, int M, int I, int K, qtts_stream_t stream) {
-    QCHECK(ldo >= I, "linear_swiglu: out row stride %d < I=%d", ldo, I);
-    return launch_linear(true, x, ldx, w_gate_up_packed, nullptr, nullptr, 0, norm_w, eps, out, ldo, M, 2 * I, K,
-                         (hipStream_t)stream);
-}
-
-
-// ------------------------------------------------------------------ linear v2 (decoder stack GEMM)
-// One kernel shape for every projection of the decoder stack.  Workgroup = NW <= 8 waves, wave w owns
+// ------------------------------------------------------------------ linear (skinny GEMM on MFMA)
+// One kernel shape for every projection.  Workgroup = NW <= 8 waves, wave w owns
 // k-steps [w*KSW, (w+1)*KSW); the workgroup walks `tiles_per_wg` consecutive 16-row weight tiles, the
 // next tile's fragments already in flight (double buffer) while the current tile is multiplied, reduced
 // across waves through LDS and written by wave 0.  Activation prologues (PRO):
@@ -354,8 +157,8 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
     return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
 }
 
-// EPI: 0 = bias/residual epilogue; 1 = SwiGLU pair: even tiles are gate rows, odd tiles the up rows of the same
-// 16 outputs (qtts_pack_gate_up order), out[m][16*(t/2)..] = bf16(bf16(silu(bf16 gate)) * bf16 up).
+// EPI: 0 = bias/residual epilogue; 1 = SwiGLU: a tile's rows 0..7 are gate rows and rows 8..15 the up rows of the
+// same 8 outputs (qtts_pack_gate_up order), out[m][8*t + j] = bf16(bf16(silu(bf16 gate_j)) * bf16 up_j).
 template <int KSW, int PRO, bool DB, int EPI>
 __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
     extern __shared__ float4_t smem4[];
@@ -456,7 +259,6 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
     }
 
     // ---- tile loop
-    float4_t gate_sum = {0.f, 0.f, 0.f, 0.f};
     auto tile_body = [&](const int cur, const int t, const int it) {
         if (DB && t + 1 < t_end) {
             const uint4 *wptr = p.wp + ((size_t)(t + 1) * KS + ks0) * 64 + lane;
@@ -475,18 +277,20 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
             float4_t sum = red[lane];
             for (int w = 1; w < NW; ++w) sum += red[w * 64 + lane];
             if (EPI == 1) {
-                if ((t & 1) == 0) {
-                    gate_sum = sum;
-                } else if (mvalid) {
-                    float v[4];
+                if (g < 2) {                              // lanes 0..31 hold gate rows; the up rows sit 32 lanes on
+                    float4_t ups = red[lane + 32];
+                    for (int w = 1; w < NW; ++w) ups += red[w * 64 + lane + 32];
+                    if (mvalid) {
+                        float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float gv = rbf(gate_sum[j]);
-                        const float sv = rbf(gv / (1.0f + expf(-gv)));
-                        v[j] = sv * rbf(sum[j]);
+                        for (int j = 0; j < 4; ++j) {
+                            const float gv = rbf(sum[j]);
+                            const float sv = rbf(gv / (1.0f + expf(-gv)));
+                            v[j] = sv * rbf(ups[j]);
+                        }
+                        *reinterpret_cast<uint2 *>(p.out + (size_t)m * p.ldo + 8 * t + 4 * g) =
+                            make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
                     }
-                    *reinterpret_cast<uint2 *>(p.out + (size_t)m * p.ldo + 16 * (t >> 1) + 4 * g) =
-                        make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
                 }
                 return;
             }
@@ -528,7 +332,7 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     QCHECK(a.ldx % 8 == 0 && a.ldx >= (pro == 2 ? 2 * a.K : a.K), "linear: x row stride %d too small or not a multiple of 8", a.ldx);
     QCHECK(a.ldo % 4 == 0 && a.ldo >= (silu_pairs ? a.N / 2 : a.N), "linear: bad out row stride %d", a.ldo);
     QCHECK(!a.res || a.ldr >= a.N, "linear: residual row stride %d < N", a.ldr);
-    QCHECK(!silu_pairs || (a.N % 32 == 0 && !a.bias && !a.res && pro != 2), "linear: bad SwiGLU-pair arguments");
+    QCHECK(!silu_pairs || (!a.bias && !a.res && pro != 2), "linear: bad SwiGLU arguments");
     QCHECK(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.wp & 15) == 0 && ((uintptr_t)a.out & 7) == 0, "linear: misaligned pointer");
     QCHECK(pro != 1 || a.nw, "linear: norm prologue without weight");
     QCHECK(!a.xnorm_out || (a.ldxn % 8 == 0 && a.ldxn >= a.K), "linear: bad xnorm_out stride");
@@ -546,13 +350,10 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     const bool db = KSW <= 12;
     int tpw = 1;
     if (db) {
-        const int target = g_tune_t > 0 ? g_tune_t * 128 : 256;
+        const int target = g_tune_t > 0 ? g_tune_t * 64 : 256;
         tpw = (ntiles + target - 1) / target;
     }
-    if (silu_pairs) {
-        QCHECK(db, "linear: SwiGLU pairs need the double-buffered kernel (K=%d)", a.K);
-        tpw = (tpw + 1) & ~1;                       // whole gate/up pairs per workgroup
-    }
+    if (silu_pairs) QCHECK(db, "linear: the SwiGLU epilogue needs K <= 3072 (K=%d)", a.K);
     a.tiles_per_wg = tpw;
     dim3 grid((ntiles + tpw - 1) / tpw, (a.M + 15) / 16);
 #define QL2(KSW_, DB_) case KSW_: \
@@ -585,13 +386,22 @@ extern "C" int qtts_linear_fused(const void *x, int ldx, const int64_t *gather_i
     return launch_linear2(a, swiglu_input ? 2 : (norm_w ? 1 : 0), (hipStream_t)stream);
 }
 
-extern "C" int qtts_linear_swiglu_fused(const void *x, int ldx, const void *w_gate_up_packed, const void *norm_w,
-                                        float eps, void *out, int ldo, int M, int I, int K, qtts_stream_t stream) {
+extern "C" int qtts_linear(const void *x, int ldx, const void *w_packed, const void *bias, const void *residual,
+                           int ldr, const void *norm_w, float eps, void *out, int ldo, int M, int N, int K,
+                           qtts_stream_t stream) {
+    return qtts_linear_fused(x, ldx, nullptr, 0, w_packed, bias, residual, ldr, norm_w, eps, nullptr, 0, 0, out, ldo, M,
+                             N, K, stream);
+}
+
+extern "C" int qtts_linear_swiglu(const void *x, int ldx, const void *w_gate_up_packed, const void *norm_w, float eps,
+                                  void *out, int ldo, int M, int I, int K, qtts_stream_t stream) {
+    QCHECK(I > 0 && I % 8 == 0, "linear_swiglu: I=%d must be a multiple of 8", I);
+    QCHECK(ldo >= I, "linear_swiglu: out row stride %d < I=%d", ldo, I);
     LinArgs a;
     a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0;
     a.wp = (const uint4 *)w_gate_up_packed; a.bias = nullptr; a.res = nullptr; a.ldr = 0;
     a.nw = (const bf16_t *)norm_w; a.eps = eps; a.xnorm_out = nullptr; a.ldxn = 0;
-    a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = 2 * I; a.K = K; a.tiles_per_wg = 2;
+    a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = 2 * I; a.K = K; a.tiles_per_wg = 1;
     return launch_linear2(a, norm_w ? 1 : 0, (hipStream_t)stream, true);
 }
 
@@ -1584,7 +1394,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         }
         if ((rc = qtts_linear_fused(attn, Hq * 128, nullptr, 0, L.wo, nullptr, cur, H, nullptr, 0.f, nullptr, 0, 0, xa, H,
                                     N, H, Hq * 128, stream))) return rc;
-        if ((rc = qtts_linear_swiglu_fused(xa, H, L.wgu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
+        if ((rc = qtts_linear_swiglu(xa, H, L.wgu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
         if ((rc = qtts_linear_fused(act, m->inter, nullptr, 0, L.wdown, nullptr, xa, H, nullptr, 0.f, nullptr, 0, 0,
                                     xb, H, N, H, m->inter, stream))) return rc;
         // Fixed roles: xa = post-attention residual stream, xb = layer output.  The next layer reads xb

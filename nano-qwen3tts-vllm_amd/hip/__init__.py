@@ -34,7 +34,6 @@ _SIGS = {
     "qtts_attention_decode_fused": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _f, _p, _i, _i,
                                          _i, _i, _p, _p]),
     "qtts_model_forward_logits": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
-    "qtts_linear_swiglu_fused": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _p]),
     "qtts_linear_swiglu": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _p]),
     "qtts_rmsnorm": (_i, [_p, _i, _p, _f, _p, _i, _i, _i, _p]),
     "qtts_qknorm_rope_store": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
@@ -142,15 +141,6 @@ def linear_swiglu(x, w_gu_packed, I, norm_w=None, eps=1e-6, out=None):
         out = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
     check(lib.qtts_linear_swiglu(ptr(x), x.stride(0), ptr(w_gu_packed), ptr(norm_w), eps, ptr(out), out.stride(0),
                                  M, I, K, stream()), "linear_swiglu")
-    return out
-
-
-def linear_swiglu_fused(x, w_gu_packed, I, norm_w=None, eps=1e-6, out=None):
-    M, K = x.shape
-    if out is None:
-        out = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
-    check(lib.qtts_linear_swiglu_fused(ptr(x), x.stride(0), ptr(w_gu_packed), ptr(norm_w), eps, ptr(out), out.stride(0),
-                                       M, I, K, stream()), "linear_swiglu_fused")
     return out
 
 

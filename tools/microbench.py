@@ -120,7 +120,7 @@ def linear2():
         def v2():
             for w in ws:
                 if kind == "silu":
-                    hip.linear_swiglu_fused(x, w, N // 2, norm_w=nw, out=out[:, :N // 2])
+                    hip.linear_swiglu(x, w, N // 2, norm_w=nw, out=out[:, :N // 2])
                 else:
                     hip.linear_fused(x, w, N, K=K, norm_w=nw if kind == "norm" else None, residual=res if kind != "norm" else None,
                                      swiglu_input=(kind == "swiglu"), out=out)
