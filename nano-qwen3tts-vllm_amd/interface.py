@@ -1,0 +1,284 @@
+"""Qwen3TTSInterface — the API object applications hold
+(reference: P/interface.py:338-1366).
+
+What this build implements of it is the decode path: the asynchronous per-frame loop that glues
+talker and predictor through the worker clients (`generate_async`, reference :1184-1308) and the
+synchronous in-process loop (`generate`, the reference's disabled `_generate_caller_driven`,
+:1310-1366), here driven by the device-resident FrameEngine.  Turning text, speaker and
+reference audio into input embeddings (tokenizer, prompt layout, speaker encoder, codec) lives in
+third-party packages and model files that are not part of the decode path; the corresponding
+methods keep their names and signatures and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import asyncio
+import json
+import logging
+import os
+import uuid
+
+import torch
+
+from .config import Qwen3TTSConfig
+from .sampling_params import SamplingParams
+
+logger = logging.getLogger(__name__)
+
+CODEC_EOS = 2150                                  # hard-coded in the reference (P/interface.py:1233)
+
+
+def _estimate_model_params(c) -> int:
+    hd = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
+    per_layer = c.hidden_size * hd * (2 * c.num_attention_heads + 2 * c.num_key_value_heads) \
+        + 3 * c.hidden_size * c.intermediate_size + 2 * c.hidden_size + 2 * hd
+    return c.num_hidden_layers * per_layer + c.hidden_size + 2 * c.vocab_size * c.hidden_size
+
+
+def _kv_block_bytes(c, block_size: int, dtype_bytes: int) -> int:
+    hd = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
+    return 2 * c.num_hidden_layers * block_size * c.num_key_value_heads * hd * dtype_bytes
+
+
+def _compute_memory_split(model_path: str, gpu_memory_utilization: float, kvcache_block_size: int = 256) -> dict:
+    """One user-facing utilisation number -> per-engine settings (reference :87-197): the process is capped
+    at `gpu_memory_utilization` of the device, the talker claims its weights plus half of the KV blocks that
+    fit, the predictor claims the rest."""
+    cfg = Qwen3TTSConfig.from_model_dir(model_path)
+    t, p = cfg.talker_config, cfg.talker_config.code_predictor_config
+    tw = _estimate_model_params(t) * 2
+    pw = _estimate_model_params(p) * 2
+    total = torch.cuda.get_device_properties(0).total_memory if torch.cuda.is_available() else 64 << 30
+    eff = total * gpu_memory_utilization
+    t_fixed, p_fixed = int(tw * 1.5), int(pw * 1.5)
+    kb_t, kb_p = _kv_block_bytes(t, kvcache_block_size, 2), _kv_block_bytes(p, kvcache_block_size, 2)
+    budget = eff - t_fixed - p_fixed
+    if budget <= 0:
+        talker_util = max(0.05, (t_fixed + kb_t) / eff)
+    else:
+        n = budget / (kb_t + kb_p)
+        talker_util = max(0.05, min((t_fixed + n * kb_t) / eff, 0.95))
+    return {"talker_util": talker_util, "pred_util": 1.0, "predictor_util": 1.0,
+            "process_gpu_memory_fraction": gpu_memory_utilization}
+
+
+def _load_codec_embeddings(model_path: str, device):
+    """fp32 copies of the codec embedding tables the frame glue needs (the reference keeps fp32 copies of
+    the bf16 weights in the API process, P/utils/embedding_loader.py:40-50,72)."""
+    from safetensors import safe_open
+    tables = {}
+    with safe_open(os.path.join(model_path, "model.safetensors"), framework="pt", device="cpu") as f:
+        for k in f.keys():
+            if k == "talker.model.codec_embedding.weight" or k.startswith("talker.code_predictor.model.codec_embedding."):
+                tables[k] = f.get_tensor(k).float().to(device)
+    inp = tables["talker.model.codec_embedding.weight"]
+    n = sum(1 for k in tables if k.startswith("talker.code_predictor."))
+    preds = [tables[f"talker.code_predictor.model.codec_embedding.{i}.weight"] for i in range(n)]
+    return inp, preds
+
+
+class Qwen3TTSInterface:
+    def __init__(self, model_path: str, enforce_eager: bool = False, tensor_parallel_size: int = 1,
+                 gpu_memory_utilization: float = 0.9):
+        assert tensor_parallel_size == 1, "one replica per GPU: tensor_parallel_size must be 1"
+        self.model_path = model_path
+        self.enforce_eager = self._enforce_eager = enforce_eager
+        self.tensor_parallel_size = self._tensor_parallel_size = tensor_parallel_size
+        self._gpu_memory_utilization = gpu_memory_utilization
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.model_config = Qwen3TTSConfig.from_model_dir(model_path)
+        self.input_embedding_weight, self.predictor_embedding_weights = _load_codec_embeddings(model_path, self.device)
+        self.input_embedding = lambda ids: self.input_embedding_weight[ids]
+        self.predictor_input_embeddings = [(lambda ids, w=w: w[ids]) for w in self.predictor_embedding_weights]
+        self.text_embedding = self.text_projection = self.processor = None      # prompt front-end: not in this build
+        self.speech_tokenizer = None
+        self.speaker_encoder = None
+        self.talker_llm = self.predictor_llm = None
+        self._use_mp_engines = True
+        self._mp_holder = None
+        self._request_queues: dict[str, asyncio.Queue] = {}
+        self._queues_lock = asyncio.Lock()
+        self._zmq_tasks: list[asyncio.Task] = []
+        self._zmq_tasks_started = False
+        self._frame_engine = None
+        self.do_sample = True            # the reference always samples (T=1.0 talker, T=0.9 predictor, top-k 50)
+        self.max_frames = 1024           # explicit stop: the reference has no length guard (ends only on codec EOS)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, *, cache_dir=None, force_download=False,
+                        local_files_only=False, token=None, revision=None, enforce_eager: bool = False,
+                        tensor_parallel_size: int = 1, gpu_memory_utilization: float = 0.9, **_):
+        """Local directories are used as they are; a non-existent absolute path is an error; anything else
+        is a hub id (reference :226-336) — there is no network here, so hub ids need a populated cache."""
+        path = pretrained_model_name_or_path
+        if os.path.isdir(path):
+            return cls(path, enforce_eager, tensor_parallel_size, gpu_memory_utilization)
+        if os.path.isabs(path):
+            raise ValueError(f"model path does not exist: {path}")
+        try:
+            from huggingface_hub import snapshot_download
+            path = snapshot_download(path, cache_dir=cache_dir, force_download=force_download,
+                                     local_files_only=local_files_only, token=token, revision=revision)
+        except Exception as e:
+            raise ValueError(f"cannot resolve model {pretrained_model_name_or_path!r}: {e}") from e
+        return cls(path, enforce_eager, tensor_parallel_size, gpu_memory_utilization)
+
+    def shutdown(self):
+        if self._frame_engine is not None:
+            self._frame_engine.exit()
+            self._frame_engine = None
+
+    # ---------------------------------------------------------------- async path (workers)
+    async def start_zmq_tasks(self) -> None:
+        if self._zmq_tasks_started:
+            return
+        self._zmq_tasks_started = True
+        from .workers.client_bridge import start_multiprocess_engines
+        from .zmq.engine_loop_mp import run_predictor_loop_mp, run_talker_loop_mp
+        holder = start_multiprocess_engines(self.model_path, self._request_queues, self._queues_lock,
+                                            gpu_memory_utilization=self._gpu_memory_utilization,
+                                            enforce_eager=self._enforce_eager,
+                                            tensor_parallel_size=self._tensor_parallel_size)
+        self._mp_holder = holder
+        self._zmq_tasks += [
+            asyncio.create_task(run_talker_loop_mp(holder.talker_client, self._request_queues, self._queues_lock,
+                                                   holder.talker_ready)),
+            asyncio.create_task(run_predictor_loop_mp(holder.predictor_client, self._request_queues, self._queues_lock,
+                                                      holder.predictor_ready))]
+        await asyncio.sleep(0.05)
+
+    async def stop_zmq_tasks(self) -> None:
+        if not self._zmq_tasks:
+            return
+        for t in self._zmq_tasks:
+            t.cancel()
+        await asyncio.gather(*self._zmq_tasks, return_exceptions=True)
+        self._zmq_tasks.clear()
+        if self._mp_holder is not None:
+            await self._mp_holder.stop_async()
+            self._mp_holder = None
+        self._zmq_tasks_started = False
+
+    def _glue_next(self, last_id: int, pred_token_ids: list[int], trailing_text_hiddens, tts_pad_embed, step: int):
+        """Sum of the 16 codebook embeddings plus the text / pad hidden, fp32 (reference :1276-1285)."""
+        last_id_hidden = self.input_embedding(torch.tensor([last_id], device=self.device)).unsqueeze(0)
+        hiddens = [last_id_hidden] + [self.predictor_input_embeddings[i](torch.tensor([pred_token_ids[i]], device=self.device)).unsqueeze(0)
+                                      for i in range(len(pred_token_ids))]
+        nxt = torch.cat(hiddens, dim=1).sum(1, keepdim=True)
+        if step < trailing_text_hiddens.shape[1]:
+            return nxt + trailing_text_hiddens[:, step].unsqueeze(1)
+        return nxt + tts_pad_embed
+
+    async def generate_async(self, inputs_embeds: torch.Tensor, trailing_text_hiddens: torch.Tensor,
+                             tts_pad_embed: torch.Tensor, talker_attention_mask: torch.Tensor | None = None,
+                             request_id: str | None = None):
+        """Async generator of 16-id frames.  `await start_zmq_tasks()` first."""
+        if not (self._use_mp_engines and self._mp_holder is not None):
+            raise RuntimeError("generate_async requires start_zmq_tasks() to be called first")
+        tsp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=self.do_sample)
+        psp = SamplingParams(temperature=0.9, max_tokens=17, do_sample=self.do_sample)
+        request_id = request_id or str(uuid.uuid4())
+        q: asyncio.Queue = asyncio.Queue()
+        async with self._queues_lock:
+            self._request_queues[request_id] = q
+        tc, pc = self._mp_holder.talker_client, self._mp_holder.predictor_client
+        try:
+            nxt = inputs_embeds if inputs_embeds.dim() == 3 else inputs_embeds.unsqueeze(0)
+            trailing_text_hiddens = trailing_text_hiddens.to(self.device).float()
+            tts_pad_embed = tts_pad_embed.to(self.device).float()
+            step = 0
+            tc.send_add_request(request_id, [nxt], tsp)
+            while step < self.max_frames:
+                engine_type, msg_type, payload = await q.get()
+                if engine_type == "talker" and msg_type == "done":
+                    break
+                if not (engine_type == "talker" and msg_type == "token"):
+                    continue
+                last_id = payload["token_ids"][-1]
+                if last_id == CODEC_EOS:
+                    break
+                last_id_hidden = self.input_embedding(torch.tensor([last_id], device=self.device)).unsqueeze(0)
+                h = torch.as_tensor(payload["hidden_states"]).to(self.device).float().reshape(1, 1, -1)
+                pc.send_add_request(request_id, [torch.cat((h, last_id_hidden), dim=1)], psp)
+                _, _, payload2 = await q.get()
+                pred_ids = payload2.get("token_ids", [])
+                yield [last_id] + pred_ids
+                nxt = self._glue_next(last_id, pred_ids, trailing_text_hiddens, tts_pad_embed, step)
+                step += 1
+                tc.send_add_request(request_id, [nxt], tsp)
+        finally:
+            try:
+                tc.send_clear_request(request_id)
+                pc.send_clear_request(request_id)
+            except Exception:
+                pass
+            async with self._queues_lock:
+                self._request_queues.pop(request_id, None)
+
+    # ---------------------------------------------------------------- sync path (in-process frame engine)
+    def _engine(self, max_streams: int = 8):
+        if self._frame_engine is None:
+            from .engine.frame_engine import FrameEngine
+            self._frame_engine = FrameEngine(self.model_path, max_streams=max_streams, enforce_eager=self._enforce_eager,
+                                             gpu_memory_utilization=self._gpu_memory_utilization / 2.0,
+                                             codec_eos=CODEC_EOS)
+        return self._frame_engine
+
+    def generate(self, inputs_embeds: torch.Tensor, trailing_text_hiddens: torch.Tensor, tts_pad_embed: torch.Tensor,
+                 talker_attention_mask: torch.Tensor | None = None, request_id: str | None = None,
+                 max_frames: int | None = None):
+        """Synchronous generator of 16-id frames for one request, everything between frames on the device."""
+        return self._generate_caller_driven(inputs_embeds, trailing_text_hiddens, tts_pad_embed,
+                                            request_id or str(uuid.uuid4()),
+                                            SamplingParams(temperature=1.0, max_tokens=1, do_sample=self.do_sample),
+                                            SamplingParams(temperature=0.9, max_tokens=17, do_sample=self.do_sample),
+                                            max_frames=max_frames)
+
+    def _generate_caller_driven(self, inputs_embeds, trailing_text_hiddens, tts_pad_embed, request_id,
+                                talker_sampling_params, predictor_sampling_params, max_frames: int | None = None):
+        fe = self._engine()
+        prompt = inputs_embeds.reshape(-1, inputs_embeds.shape[-1])
+        budget = fe.tr.config.max_model_len - prompt.shape[0] - 2
+        n = min(max_frames or self.max_frames, budget)
+        text = trailing_text_hiddens.reshape(-1, trailing_text_hiddens.shape[-1]).float()
+        pad = tts_pad_embed.reshape(1, -1).float().to(text.device)
+        text_adds = torch.cat([text, pad], 0)                     # last row (pad) repeats after the text runs out
+        sid = fe.add_stream(prompt, text_adds, max_frames=n, talker_sampling=talker_sampling_params,
+                            predictor_sampling=predictor_sampling_params, sid=request_id)
+        try:
+            for _ in range(n):
+                res = fe.step()
+                if sid not in res:
+                    return
+                yield res[sid]
+        finally:
+            fe.remove_stream(sid)
+
+    # ---------------------------------------------------------------- text / audio front-end (not in this build)
+    def _front_end(self, what: str):
+        raise NotImplementedError(
+            f"{what}: building input embeddings from text / speakers / reference audio needs the tokenizer, the "
+            "text embedding tables and the speech codec, which are outside this build's decode path; call "
+            "generate()/generate_async() with inputs_embeds, trailing_text_hiddens and tts_pad_embed instead")
+
+    def generate_custom_voice(self, text: str, language: str = "English", speaker: str = "Vivian"):
+        self._front_end("generate_custom_voice")
+
+    async def generate_custom_voice_async(self, text: str, language: str = "English", speaker: str = "Vivian"):
+        self._front_end("generate_custom_voice_async")
+        yield []          # pragma: no cover
+
+    def generate_voice_design(self, text: str, instruct: str, language: str | None = None, non_streaming_mode: bool = True):
+        self._front_end("generate_voice_design")
+
+    def generate_voice_clone(self, text: str, language: str = "English", ref_audio=None, ref_text=None,
+                             x_vector_only_mode: bool = False, voice_clone_prompt=None, non_streaming_mode: bool = True):
+        self._front_end("generate_voice_clone")
+
+    async def generate_voice_clone_async(self, text: str, language: str = "English", ref_audio=None, ref_text=None,
+                                         x_vector_only_mode: bool = False, voice_clone_prompt=None,
+                                         non_streaming_mode: bool = True):
+        self._front_end("generate_voice_clone_async")
+        yield []          # pragma: no cover
+
+    def create_voice_clone_prompt(self, ref_audio, ref_text=None, x_vector_only_mode: bool = False):
+        self._front_end("create_voice_clone_prompt")

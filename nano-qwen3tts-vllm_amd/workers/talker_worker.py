@@ -1,0 +1,95 @@
+"""Talker worker: a synchronous command loop around TalkerLLM
+(reference: P/workers/talker_worker.py:42-184).  `serve` is transport-agnostic (any
+recv()/send(bytes) pair); `run_talker_worker` wires it to the reference's ZMQ
+PULL/PUSH sockets."""
+from __future__ import annotations
+
+import logging
+import sys
+
+import torch
+
+from .protocol import (CMD_ADD_REQUEST, CMD_CLEAR_REQUEST, CMD_RUN_STEP, CMD_SHUTDOWN, deserialize_command,
+                       sampling_params_from_dict, serialize_talker_result)
+
+logger = logging.getLogger(__name__)
+_sampling_params_from_dict = sampling_params_from_dict
+
+
+def serve(talker_llm, recv, send, device=None) -> int:
+    """Run until a shutdown command arrives.  Returns the number of steps served.  A failing step
+    still answers (with an empty result, so the API loop does not hang) and then re-raises."""
+    device = device or ("cuda" if torch.cuda.is_available() else "cpu")
+    steps = 0
+    while True:
+        cmd = deserialize_command(recv())
+        kind = cmd.get("cmd")
+        if kind == CMD_SHUTDOWN:
+            return steps
+        if kind == CMD_ADD_REQUEST:
+            embeds = [torch.from_numpy(a).to(device) for a in cmd["inputs_embeds"]]
+            talker_llm.add_request(embeds, sampling_params_from_dict(cmd.get("sampling_params", {})),
+                                   request_id=cmd["request_id"])
+        elif kind == CMD_CLEAR_REQUEST:
+            talker_llm.clear_request(cmd["request_id"])
+        elif kind == CMD_RUN_STEP:
+            try:
+                _, _, outputs_all = talker_llm.step_with_outputs()
+            except Exception:
+                logger.exception("[talker_worker] step failed")
+                send(serialize_talker_result(cmd["step_id"], []))
+                raise
+            send(serialize_talker_result(cmd["step_id"], outputs_all))
+            steps += 1
+        else:
+            logger.warning("[talker_worker] unknown command: %r", kind)
+
+
+def run_talker_worker(command_connect_addr: str, result_connect_addr: str, model_path: str, *,
+                      gpu_memory_utilization: float = 0.9, enforce_eager: bool = False,
+                      tensor_parallel_size: int = 1) -> None:
+    try:
+        import zmq
+    except ImportError as e:
+        raise ImportError("pyzmq is required for the talker worker process") from e
+    from ..interface import _compute_memory_split
+    from ..llm import TalkerLLM
+    mem = _compute_memory_split(model_path, gpu_memory_utilization)
+    talker_llm = TalkerLLM(model_path, enforce_eager=enforce_eager, tensor_parallel_size=tensor_parallel_size,
+                           gpu_memory_utilization=min(mem["talker_util"], 0.85),
+                           process_gpu_memory_fraction=mem["process_gpu_memory_fraction"])
+    ctx = zmq.Context()
+    pull, push = ctx.socket(zmq.PULL), ctx.socket(zmq.PUSH)
+    for s, addr in ((pull, command_connect_addr), (push, result_connect_addr)):
+        s.setsockopt(zmq.LINGER, 0)
+        s.connect(addr)
+    try:
+        serve(talker_llm, pull.recv, push.send)
+    finally:
+        pull.close()
+        push.close()
+        ctx.term()
+        try:
+            talker_llm.exit()
+        except Exception:
+            pass
+
+
+def main():
+    import argparse
+    p = argparse.ArgumentParser()
+    p.add_argument("--command_connect", required=True)
+    p.add_argument("--result_connect", required=True)
+    p.add_argument("--model_path", required=True)
+    p.add_argument("--gpu_memory_utilization", type=float, default=0.9)
+    p.add_argument("--enforce_eager", action="store_true")
+    p.add_argument("--tensor_parallel_size", type=int, default=1)
+    a = p.parse_args()
+    logging.basicConfig(level=logging.INFO)
+    run_talker_worker(a.command_connect, a.result_connect, a.model_path, gpu_memory_utilization=a.gpu_memory_utilization,
+                      enforce_eager=a.enforce_eager, tensor_parallel_size=a.tensor_parallel_size)
+
+
+if __name__ == "__main__":
+    main()
+    sys.exit(0)

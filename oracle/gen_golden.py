@@ -344,7 +344,33 @@ def main():
     gen_models(ref, syn, "tiny", 11, "tiny")
     gen_models(ref, syn, "tiny-id", 12, "tiny_id")
     gen_sched(ref)
+    gen_protocol(ref)
+
+
+def gen_protocol(ref):
+    """Wire-format fixtures: the bytes the reference's own serializers emit."""
+    proto = importlib.import_module("nano_qwen3tts_vllm.workers.protocol")
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(1, 3, 8, generator=g).bfloat16()
+    hid = torch.randn(8, generator=g).bfloat16()
+    sp = {"temperature": 0.9, "max_tokens": 17, "ignore_eos": False, "do_sample": True, "top_k": 50, "top_p": 1.0}
+    msgs = {
+        "talker_add": proto.serialize_talker_add_request("req-1", [emb], sp),
+        "predictor_add": proto.serialize_predictor_add_request("req-1", [emb.float()], sp),
+        "run_step": proto.serialize_talker_run_step("step-7"),
+        "clear": proto.serialize_clear_request("req-1"),
+        "shutdown": proto.serialize_shutdown(),
+        "talker_result": proto.serialize_talker_result("step-7", [("req-1", 3, [11, 12], hid, False)]),
+        "predictor_result": proto.serialize_predictor_result("step-8", [("req-1", 4, list(range(15)))]),
+    }
+    np.savez(os.path.join(OUT, "protocol.npz"), emb=f32(emb), hid=f32(hid),
+             **{k: np.frombuffer(v, dtype=np.uint8) for k, v in msgs.items()})
+    print("protocol.npz", {k: len(v) for k, v in msgs.items()})
 
 
 if __name__ == "__main__":
-    main()
+    if "--protocol-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        gen_protocol(ref_harness.load_reference())
+    else:
+        main()

@@ -1,0 +1,213 @@
+"""CPU: wire protocol against the reference's own bytes, worker command loops, the asyncio
+orchestrator loops and Qwen3TTSInterface.generate_async — driven with deterministic fake
+engines (no GPU, no pyzmq)."""
+import asyncio
+import os
+import queue
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_npz
+from nano_qwen3tts_vllm.sampling_params import SamplingParams
+from nano_qwen3tts_vllm.utils import synthetic
+from nano_qwen3tts_vllm.workers import predictor_worker, protocol as P, talker_worker
+
+
+# ------------------------------------------------------------------ protocol
+def test_protocol_matches_reference_bytes():
+    g = load_npz("protocol.npz")
+    emb = torch.from_numpy(g["emb"]).bfloat16()
+    hid = torch.from_numpy(g["hid"]).bfloat16()
+    sp = {"temperature": 0.9, "max_tokens": 17, "ignore_eos": False, "do_sample": True, "top_k": 50, "top_p": 1.0}
+    mine = {
+        "talker_add": P.serialize_talker_add_request("req-1", [emb], sp),
+        "predictor_add": P.serialize_predictor_add_request("req-1", [emb.float()], sp),
+        "run_step": P.serialize_talker_run_step("step-7"),
+        "clear": P.serialize_clear_request("req-1"),
+        "shutdown": P.serialize_shutdown(),
+        "talker_result": P.serialize_talker_result("step-7", [("req-1", 3, [11, 12], hid, False)]),
+        "predictor_result": P.serialize_predictor_result("step-8", [("req-1", 4, list(range(15)))]),
+    }
+    for k, b in mine.items():
+        assert b == g[k].tobytes(), k          # byte-identical to what the reference emits
+    cmd = P.deserialize_command(g["talker_add"].tobytes())
+    assert cmd["cmd"] == "add_request" and cmd["request_id"] == "req-1" and cmd["sampling_params"] == sp
+    assert cmd["inputs_embeds"][0].dtype == np.float32 and np.array_equal(cmd["inputs_embeds"][0], g["emb"])
+    step_id, outs = P.deserialize_talker_result(g["talker_result"].tobytes())
+    assert step_id == "step-7" and outs[0][:3] == ("req-1", 3, [11, 12]) and np.array_equal(outs[0][3], g["hid"])
+    assert P.sampling_params_to_dict(P.sampling_params_from_dict(sp)) == sp
+
+
+# ------------------------------------------------------------------ fake engines
+class FakeTalker:
+    """Token = hash of the fed embedding; hidden = mean row.  Same API as TalkerLLM."""
+
+    def __init__(self, *a, **k):
+        self.seqs, self.cleared, self.exited = {}, [], False
+
+    def add_request(self, inputs_embeds, sampling_params, request_id=None):
+        for e in inputs_embeds:
+            st = self.seqs.setdefault(request_id, {"toks": [], "pending": None, "sid": len(self.seqs)})
+            st["pending"] = e.float().reshape(-1, e.shape[-1])
+
+    def clear_request(self, request_id):
+        self.cleared.append(request_id)
+        self.seqs.pop(request_id, None)
+
+    def step_with_outputs(self):
+        out = []
+        for rid, st in self.seqs.items():
+            if st["pending"] is None:
+                continue
+            x = st["pending"]
+            st["pending"] = None
+            tok = int(x.abs().sum().item() * 1000) % 500
+            st["toks"].append(tok)
+            out.append((rid, st["sid"], list(st["toks"]), x.mean(0).to(torch.bfloat16), False))
+        return [], -len(out), out
+
+    def exit(self):
+        self.exited = True
+
+
+class _Sched:
+    def __init__(self):
+        self.waiting, self.running = [], []
+
+
+class FakePredictor:
+    def __init__(self, *a, **k):
+        self.scheduler, self.cleared, self.exited = _Sched(), [], False
+
+    def add_request(self, inputs_embeds, sampling_params, request_id=None):
+        for e in inputs_embeds:
+            self.scheduler.waiting.append((request_id, e.float()))
+
+    def clear_request(self, request_id):
+        self.cleared.append(request_id)
+
+    def step(self):
+        outs = []
+        for i, (rid, e) in enumerate(self.scheduler.waiting):
+            base = int(e.abs().sum().item() * 100)
+            outs.append((rid, i, [(base + 7 * k) % 256 for k in range(15)]))
+        self.scheduler.waiting.clear()
+        return outs, len(outs)
+
+    def exit(self):
+        self.exited = True
+
+
+def test_worker_command_loops():
+    """serve(): add_request / run_step / clear_request / shutdown over an in-memory transport."""
+    inbox, outbox = queue.Queue(), queue.Queue()
+    t = FakeTalker()
+    sp = P.sampling_params_to_dict(SamplingParams(temperature=1.0, max_tokens=1))
+    e = torch.ones(1, 4, 8)
+    for msg in (P.serialize_talker_add_request("a", [e], sp), P.serialize_talker_run_step("s1"),
+                P.serialize_talker_add_request("a", [e[:, :1] * 2], sp), P.serialize_talker_run_step("s2"),
+                P.serialize_clear_request("a"), P.serialize_talker_run_step("s3"), P.serialize_shutdown()):
+        inbox.put(msg)
+    assert talker_worker.serve(t, inbox.get, outbox.put, device="cpu") == 3
+    r1, r2, r3 = (P.deserialize_talker_result(outbox.get()) for _ in range(3))
+    assert r1[0] == "s1" and r1[1][0][2] == [32000 % 500] and r1[1][0][3].dtype == np.float32
+    assert r2[1][0][2] == [32000 % 500, 16000 % 500]
+    assert r3 == ("s3", []) and t.cleared == ["a"]
+
+    p = FakePredictor()
+    inbox.put(P.serialize_predictor_add_request("a", [torch.ones(1, 2, 8)], sp))
+    inbox.put(P.serialize_predictor_add_request("b", [torch.ones(1, 2, 8) * 2], sp))
+    inbox.put(P.serialize_predictor_run_step("b1"))
+    inbox.put(P.serialize_shutdown())
+    assert predictor_worker.serve(p, inbox.get, outbox.put, device="cpu") == 1
+    sid, outs = P.deserialize_predictor_result(outbox.get())
+    assert sid == "b1" and [o[0] for o in outs] == ["a", "b"] and all(len(o[2]) == 15 for o in outs)
+
+    class Boom(FakeTalker):
+        def step_with_outputs(self):
+            raise RuntimeError("boom")
+    inbox.put(P.serialize_talker_run_step("s9"))
+    with pytest.raises(RuntimeError):
+        talker_worker.serve(Boom(), inbox.get, outbox.put, device="cpu")
+    assert P.deserialize_talker_result(outbox.get()) == ("s9", [])       # an empty answer precedes the crash
+
+
+# ------------------------------------------------------------------ interface + orchestrator loops
+@pytest.fixture(scope="module")
+def model_dir(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("tiny_model"))
+    synthetic.write_model_dir(d, "tiny", seed=3, embed_std=0.05)
+    return d
+
+
+def expected_frames(iface, prompt, trailing, pad, n):
+    """The loop of P/interface.py:1210-1299 written out against the fake engines' arithmetic."""
+    t, p = FakeTalker(), FakePredictor()
+    frames = []
+    x = prompt
+    for step in range(n):
+        t.add_request([x], None, "r")
+        _, _, outs = t.step_with_outputs()
+        tok, hid = outs[0][2][-1], outs[0][3].float()
+        emb = iface.input_embedding_weight[tok].cpu()
+        p.add_request([torch.stack([hid, emb]).unsqueeze(0)], None, "r")
+        ptoks = p.step()[0][0][2]
+        frames.append([tok] + ptoks)
+        s = torch.stack([emb] + [iface.predictor_embedding_weights[i][ptoks[i]].cpu() for i in range(15)]).unsqueeze(0).sum(1, keepdim=True)
+        x = s + (trailing[:, step].unsqueeze(1) if step < trailing.shape[1] else pad)
+    return frames
+
+
+def test_interface_generate_async_with_inprocess_clients(model_dir, monkeypatch):
+    import nano_qwen3tts_vllm.llm as llm
+    from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
+    monkeypatch.setenv("QTTS_INPROCESS", "1")
+    monkeypatch.setattr(llm, "TalkerLLM", FakeTalker)
+    monkeypatch.setattr(llm, "PredictorLLM", FakePredictor)
+    iface = Qwen3TTSInterface.from_pretrained(model_dir)
+    iface.max_frames = 5
+    H = iface.model_config.talker_config.hidden_size
+    gen = torch.Generator().manual_seed(1)
+    prompts = [torch.randn(1, L, H, generator=gen) for L in (6, 9, 4)]
+    trailing = torch.randn(1, 3, H, generator=gen)
+    pad = torch.randn(1, 1, H, generator=gen)
+
+    async def run():
+        with pytest.raises(RuntimeError):
+            async for _ in iface.generate_async(prompts[0], trailing, pad, None):
+                pass
+        await iface.start_zmq_tasks()
+        await iface.start_zmq_tasks()                      # idempotent
+
+        async def one(pr):
+            return [f async for f in iface.generate_async(pr, trailing, pad, None)]
+        res = await asyncio.gather(*[one(pr) for pr in prompts])      # three concurrent requests
+        # a consumer that stops early must release its request on both engines
+        agen = iface.generate_async(prompts[0], trailing, pad, None, request_id="early")
+        first = await agen.__anext__()
+        await agen.aclose()
+        holder = iface._mp_holder
+        await iface.stop_zmq_tasks()
+        return res, first, holder
+
+    res, first, holder = asyncio.run(run())
+    for pr, got in zip(prompts, res):
+        assert got == expected_frames(iface, pr, trailing, pad, 5)
+        assert all(len(f) == 16 for f in got)
+    assert first == res[0][0]
+    assert "early" in holder.talker_client._engine.cleared and "early" in holder.predictor_client._engine.cleared
+    assert holder.talker_client._engine.exited and holder.predictor_client._engine.exited
+    assert not iface._request_queues
+
+
+def test_interface_rejects_missing_path_and_front_end(model_dir):
+    from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
+    with pytest.raises(ValueError):
+        Qwen3TTSInterface.from_pretrained("/nonexistent/model/dir")
+    iface = Qwen3TTSInterface(model_dir)
+    with pytest.raises(NotImplementedError):
+        iface.generate_voice_design("hi", "a calm voice")
+    with pytest.raises(AssertionError):
+        Qwen3TTSInterface(model_dir, tensor_parallel_size=2)
