@@ -114,6 +114,38 @@ def cpu_baseline(cfg, tw, pw, B, frames, prompt_len):
                        f"{frames} frames, {dt:.1f} s")
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected separately, FETCH_SIZE doubled as gfx950 requires); None when the file is absent.
+    Counters cannot be read from inside this process, so the figure is the one measured on the same kernel
+    and shape by tools/microbench.py dominant."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def dist_env():
+    """(rank, world, local_rank) as torch.distributed.run exports them; a plain `python bench.py` is rank 0 of 1."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def max_over_ranks(elapsed: float, world: int, device=None) -> float:
+    """Replicas are independent: the job's time is the slowest rank's."""
+    if world <= 1:
+        return elapsed
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_tokens(streams_per_gpu: int, steps: int, world: int) -> int:
+    """16 codes per frame per stream, every rank runs `streams_per_gpu` streams for `steps` frames (weak scaling)."""
+    return 16 * streams_per_gpu * steps * world
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,9 +157,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=40)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local = dist_env()
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -182,14 +212,11 @@ def main():
     fe.run_frames(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, world, device)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        tokens = 16 * B * args.steps * world
+        tokens = whole_job_tokens(B, args.steps, world)
         value = tokens / elapsed
         mean_ctx = sum(prompt_lens) / B + 1 + args.warmup + 1 + args.steps / 2
         bytes_frame = algorithmic_bytes_per_frame(cfg, B, mean_ctx)
@@ -210,7 +237,7 @@ def main():
                                "unit": "GB/s", "frac": bytes_frame / (ms_per_step * 1e-3) / HBM_PEAK},
             "roofline": {"bound": "hbm", "kernel": "linear2_kernel<8,1,true,1> (talker RMSNorm + gate/up GEMM + SwiGLU launch)",
                          "achieved": kbytes / ksec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": kbytes / ksec / HBM_PEAK, "traffic": None, "bytes_per_launch": kbytes,
+                         "frac": kbytes / ksec / HBM_PEAK, "traffic": pmc_traffic(), "bytes_per_launch": kbytes,
                          "us_per_launch": ksec * 1e6},
         }
         if not args.no_cpu_baseline:

@@ -138,6 +138,23 @@ def linear2():
         print(line, flush=True)
 
 
+def dominant():
+    """The dominant kernel of the path alone (talker RMSNorm + gate/up GEMM + SwiGLU launch, 1.7B shape, 8 rows),
+    cycling through 28 weight buffers — the workload the PMC traffic passes are collected on."""
+    B, H, I = 8, 2048, 6144
+    ws = [torch.randn(2 * I * H, device=dev).bfloat16() * 0.02 for _ in range(28)]
+    x = torch.randn(B, H, device=dev).bfloat16()
+    nw = torch.ones(H, device=dev).bfloat16()
+    out = torch.empty(B, I, dtype=torch.bfloat16, device=dev)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(10):
+            for w in ws:
+                hip.linear_swiglu(x, w, I, norm_w=nw, out=out)
+        st.synchronize()
+    print("launches", 280, "algorithmic bytes per launch", 2 * I * H * 2 + B * H * 2 + B * I * 2, flush=True)
+
+
 def frame():
     import json, tempfile
     sys.path.insert(0, ROOT)
@@ -177,4 +194,4 @@ def frame():
 
 
 if __name__ == "__main__":
-    {"launch": launch, "linear": linear, "linear2": linear2, "frame": frame}[sys.argv[1]]()
+    {"launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant}[sys.argv[1]]()
