@@ -127,7 +127,9 @@ extern "C" int qtts_pack_gate_up(const void *gate, const void *up, void *packed,
 
 static int g_tune_ksw = 0;   // 0 = automatic
 static int g_tune_t = 0;
+static int g_dbg_linear = 0;
 extern "C" void qtts_tune_linear(int ksw, int t) { g_tune_ksw = ksw; g_tune_t = t; }
+extern "C" void qtts_debug_linear(int flags) { g_dbg_linear = flags; }
 
 // ------------------------------------------------------------------ linear (skinny GEMM on MFMA)
 // One kernel shape for every projection.  Workgroup = NW <= 8 waves, wave w owns
@@ -147,6 +149,7 @@ struct LinArgs {
     bf16_t *xnorm_out; int ldxn;
     bf16_t *out; int ldo;
     int M, N, K, tiles_per_wg;
+    int dbg;      // tuning experiments only (0 in production): bit0 every tile reads weight tile 0, bit1 skip x loads
 };
 
 __device__ __forceinline__ void unpack2(uint32_t w, float &a, float &b) {
@@ -174,13 +177,6 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
     const int t_begin = blockIdx.x * p.tiles_per_wg;
     const int t_end = min(t_begin + p.tiles_per_wg, ntiles);
 
-    Frag a[DB ? 2 : 1][KSW];
-    {
-        const uint4 *wptr = p.wp + ((size_t)t_begin * KS + ks0) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < KSW; ++i) a[0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
-    }
-
     // ---- activation prologue
     Frag xb[KSW];
     size_t xrow = 0;
@@ -195,7 +191,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
 #pragma unroll
     for (int i = 0; i < KSW; ++i) {
         const int k = 32 * (ks0 + i) + 8 * g;
-        if (!mvalid) {
+        if (!mvalid || (p.dbg & 2)) {
             xb[i].u = make_uint4(0, 0, 0, 0);
         } else if (PRO == 2) {
             Frag ga, up;
@@ -215,6 +211,15 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
             xb[i].u = *reinterpret_cast<const uint4 *>(p.x + xrow + k);
         }
     }
+    // The (small) activation loads above go out first: vector memory requests of a wave are served in order, so
+    // behind KSW KiB of weight requests they would arrive last although everything else waits for them.
+    Frag a[DB ? 2 : 1][KSW];
+    {
+        const uint4 *wptr = p.wp + ((size_t)((p.dbg & 1) ? 0 : t_begin) * KS + ks0) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) a[0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
+    }
+
     float *normred = reinterpret_cast<float *>(smem4 + (size_t)2 * NW * 64);
     if (PRO == 1) {
         uint4 nwv[KSW];                                  // requested before the barrier so both L2 trips overlap
@@ -260,8 +265,15 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
 
     // ---- tile loop
     auto tile_body = [&](const int cur, const int t, const int it) {
+        // residual / bias words of this tile are requested up front by the wave that will need them, so the
+        // epilogue does not start another memory round trip after the reduction
+        uint2 resw = make_uint2(0, 0), biasw = make_uint2(0, 0);
+        if (EPI == 0 && wave == 0) {
+            if (p.res && mvalid) resw = *reinterpret_cast<const uint2 *>(p.res + (size_t)m * p.ldr + 16 * t + 4 * g);
+            if (p.bias) biasw = *reinterpret_cast<const uint2 *>(p.bias + 16 * t + 4 * g);
+        }
         if (DB && t + 1 < t_end) {
-            const uint4 *wptr = p.wp + ((size_t)(t + 1) * KS + ks0) * 64 + lane;
+            const uint4 *wptr = p.wp + ((size_t)((p.dbg & 1) ? 0 : (t + 1)) * KS + ks0) * 64 + lane;
 #pragma unroll
             for (int i = 0; i < KSW; ++i)
                 a[DB ? (cur ^ 1) : 0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
@@ -297,13 +309,17 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
             const int n = 16 * t + 4 * g;
             if (mvalid) {
                 uint32_t o2[2];
-                float v[4];
+                float v[4], rf[4], bfv[4];
+                unpack2(resw.x, rf[0], rf[1]);
+                unpack2(resw.y, rf[2], rf[3]);
+                unpack2(biasw.x, bfv[0], bfv[1]);
+                unpack2(biasw.y, bfv[2], bfv[3]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float q = sum[j];
-                    if (p.bias) q += bf2f(p.bias[n + j]);
+                    if (p.bias) q += bfv[j];
                     q = rbf(q);
-                    if (p.res) q = q + bf2f(p.res[(size_t)m * p.ldr + n + j]);
+                    if (p.res) q = q + rf[j];
                     v[j] = q;
                 }
                 o2[0] = pack2(v[0], v[1]);
@@ -355,6 +371,7 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     }
     if (silu_pairs) QCHECK(db, "linear: the SwiGLU epilogue needs K <= 3072 (K=%d)", a.K);
     a.tiles_per_wg = tpw;
+    a.dbg = g_dbg_linear;
     dim3 grid((ntiles + tpw - 1) / tpw, (a.M + 15) / 16);
 #define QL2(KSW_, DB_) case KSW_: \
         if (silu_pairs && DB_) { if (pro == 1) launch_linear2_inst<KSW_, 1, DB_, DB_ ? 1 : 0>(grid, NW, s, a); \

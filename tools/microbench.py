@@ -138,6 +138,35 @@ def linear2():
         print(line, flush=True)
 
 
+def lat():
+    """Where a small GEMM launch spends its time: weights L2-hot (flag 1), no activation loads (flag 2), both (3)."""
+    B = 8
+    shapes = [("o pred", 1024, 2048, "res"), ("down pred", 1024, 3072, "res"), ("qkv pred", 4096, 1024, "norm"),
+              ("head pred", 2048, 1024, "norm"), ("o 1.7B", 2048, 2048, "res"), ("qkv 1.7B", 4096, 2048, "norm")]
+    for name, N, K, kind in shapes:
+        nbuf = max(2, int(600e6 // (N * K * 2)))
+        ws = [torch.randn(N * K, device=dev).bfloat16() * 0.02 for _ in range(nbuf)]
+        x = torch.randn(B, K, device=dev).bfloat16()
+        nw = torch.ones(K, device=dev).bfloat16()
+        out = torch.empty(B, N, dtype=torch.bfloat16, device=dev)
+        res = torch.randn(B, N, device=dev).bfloat16()
+        line = f"{name:10s} N={N:5d} K={K:5d} {N*K*2/1e6:5.1f} MB:"
+
+        def run():
+            for w in ws:
+                hip.linear_fused(x, w, N, K=K, norm_w=nw if kind == "norm" else None, residual=res if kind != "norm" else None, out=out)
+        for flags in (0, 1, 2, 3):
+            hip.lib.qtts_debug_linear(flags)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                run()
+                gr = hip.Graph.capture(run)
+            us = timed(lambda: gr.launch(), nbuf)
+            line += f"  dbg{flags}: {us:5.2f}us"
+        hip.lib.qtts_debug_linear(0)
+        print(line, flush=True)
+
+
 def dominant():
     """The dominant kernel of the path alone (talker RMSNorm + gate/up GEMM + SwiGLU launch, 1.7B shape, 8 rows),
     cycling through 28 weight buffers — the workload the PMC traffic passes are collected on."""
@@ -194,4 +223,4 @@ def frame():
 
 
 if __name__ == "__main__":
-    {"launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant}[sys.argv[1]]()
+    {"launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat}[sys.argv[1]]()
