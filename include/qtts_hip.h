@@ -123,7 +123,11 @@ int qtts_paged_attention(const void *q, int ldq, const void *k_cache, const void
  * P/layers/attention.py:73-96 in decode mode): per-head RMSNorm + RoPE of q and k read
  * from the raw qkv rows, the new token's K/V stored at slot_mapping[b], attention of
  * row b over context_lens[b] tokens of block_tables[b] (the newest from registers).
- * One row per sequence.  workspace as for qtts_paged_attention. */
+ * One row per sequence.  Rows longer than 128 tokens are split over workgroups whose
+ * partial results meet in `workspace` (qtts_attn_decode_workspace_bytes(B, Hq, Hkv,
+ * max_context) bytes of device scratch; may be NULL when max_context <= 128); the call
+ * clears the few counter bytes it needs, so the scratch may be reused freely between calls. */
+size_t qtts_attn_decode_workspace_bytes(int B, int Hq, int Hkv, int max_context);
 int qtts_attention_decode_fused(const void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w,
                                 float eps, const void *rope_cos, const void *rope_sin, int max_pos,
                                 const int64_t *positions, const int32_t *slot_mapping, void *k_cache,

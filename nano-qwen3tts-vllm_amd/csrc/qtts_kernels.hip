@@ -733,9 +733,13 @@ extern "C" int qtts_paged_attention(const void *q, int ldq, const void *k_cache,
 // One query row per sequence (decode).  Reads the raw q/k/v rows the qkv GEMM produced, applies the
 // per-head RMSNorm and rotary embedding in registers (same rounding points as qknorm_rope_store_kernel),
 // stores the new token's K/V into its cache slot and attends over context_lens[row] cached tokens, the
-// newest one taken from registers.  grid (rows, Hkv, nsplit), 256-token splits walked as two 128-token
-// passes; 16 lanes per token, a lane owns 8 head dims (its rotate_half partner is lane ^ 8).
-#define ATT2_SPLIT 256
+// newest one taken from registers.  grid (rows, Hkv, nsplit) with 128-token splits; 16 lanes per token,
+// a lane owns 8 head dims (its rotate_half partner is lane ^ 8); a 16-lane group scores its tokens
+// first and exponentiates against the group maximum afterwards (no per-token rescale of the accumulator).
+// Rows longer than one split leave (max, sum, weighted V) partials in the workspace; the workgroup that
+// arrives last at the row's counter merges them, so no second launch is needed.  The counters start at
+// zero and the merging workgroup puts its counter back to zero.
+#define ATT2_SPLIT 128
 struct AttnFusedArgs {
     const bf16_t *qkv; int ld;
     const bf16_t *qw, *kw; float eps;
@@ -749,6 +753,7 @@ struct AttnFusedArgs {
     bf16_t *out; int ldo;
     int Hq, Hkv;
     float *part_o, *part_ml; int nsplit;
+    int *counters;
 };
 
 __device__ __forceinline__ void norm_rope8(const float (&x)[8], const bf16_t *__restrict__ w, float eps, int l16,
@@ -773,21 +778,32 @@ __device__ __forceinline__ void norm_rope8(const float (&x)[8], const bf16_t *__
     }
 }
 
-template <int G>
-__global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnFusedArgs p) {
-    __shared__ float sm_acc[16][G][128];
-    __shared__ float sm_m[16][G];
-    __shared__ float sm_l[16][G];
+__device__ __forceinline__ float ld_agent(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int G, int NG>
+__global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFusedArgs p) {
+    constexpr int TPG = ATT2_SPLIT / NG;               // tokens a 16-lane group walks
+    constexpr int NT = NG * 16;
+    __shared__ float sm_acc[NG][G][128];
+    __shared__ float sm_m[NG][G];
+    __shared__ float sm_l[NG][G];
+    __shared__ int sm_last;
     const int row = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
     const int ctx = p.context_lens[row];
     const int Hq = p.Hq, Hkv = p.Hkv;
     const int t0 = split * ATT2_SPLIT;
     if (ctx <= 0) {
-        if (split == 0 && p.nsplit == 1)
-            for (int e = threadIdx.x; e < G * 128; e += 256) p.out[(size_t)row * p.ldo + (size_t)kvh * G * 128 + e] = 0;
+        if (split == 0)
+            for (int e = threadIdx.x; e < G * 128; e += NT) p.out[(size_t)row * p.ldo + (size_t)kvh * G * 128 + e] = 0;
         return;
     }
     if (t0 >= ctx) return;
+    const int nact = (ctx + ATT2_SPLIT - 1) / ATT2_SPLIT;   // splits of this row that hold tokens
     const int32_t *bt = p.block_tables + (size_t)row * p.max_blocks;
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const bf16_t *rowp = p.qkv + (size_t)row * p.ld;
@@ -795,24 +811,21 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnFusedA
     pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);      // metadata is device data: never index past the table
     const bf16_t *cosr = p.cosT + pos * 64, *sinr = p.sinT + pos * 64;
 
-    // cached K/V of the first pass are requested before the norm/rope arithmetic
-    Frag kk[8], vv[8];
-    auto issue_loads = [&](int base) {
+    // cached K/V are requested before the norm/rope arithmetic
+    Frag kk[TPG], vv[TPG];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int t = base + i * 16 + grp;
-            if (t < ctx - 1) {
-                const int blk = bt[t >> 8];
-                const size_t off = (((size_t)blk * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
-                kk[i].u = *reinterpret_cast<const uint4 *>(p.kc + off);
-                vv[i].u = *reinterpret_cast<const uint4 *>(p.vc + off);
-            } else {
-                kk[i].u = make_uint4(0, 0, 0, 0);
-                vv[i].u = make_uint4(0, 0, 0, 0);
-            }
+    for (int i = 0; i < TPG; ++i) {
+        const int t = t0 + i * NG + grp;
+        if (t < ctx - 1) {
+            const int blk = bt[t >> 8];
+            const size_t off = (((size_t)blk * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
+            kk[i].u = *reinterpret_cast<const uint4 *>(p.kc + off);
+            vv[i].u = *reinterpret_cast<const uint4 *>(p.vc + off);
+        } else {
+            kk[i].u = make_uint4(0, 0, 0, 0);
+            vv[i].u = make_uint4(0, 0, 0, 0);
         }
-    };
-    issue_loads(t0);
+    }
 
     float qf[G][8];
 #pragma unroll
@@ -824,70 +837,71 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnFusedA
         for (int j = 0; j < 8; ++j) x[j] = bf2f(f.h[j]);
         norm_rope8(x, p.qw, p.eps, l16, cosr, sinr, qf[h]);
     }
-    // the new token (index ctx-1): K normalised + rotated, V as is
-    float knew[8], vnew[8];
+    // the new token (index ctx-1): K normalised + rotated (exactly representable in bf16), V as is
+    Frag knew, vnew;
     {
-        Frag f, fv;
+        Frag f;
         f.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(Hq + kvh) * 128 + 8 * l16);
-        fv.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(Hq + Hkv + kvh) * 128 + 8 * l16);
-        float x[8];
+        vnew.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(Hq + Hkv + kvh) * 128 + 8 * l16);
+        float x[8], kn[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            x[j] = bf2f(f.h[j]);
-            vnew[j] = bf2f(fv.h[j]);
-        }
-        norm_rope8(x, p.kw, p.eps, l16, cosr, sinr, knew);
+        for (int j = 0; j < 8; ++j) x[j] = bf2f(f.h[j]);
+        norm_rope8(x, p.kw, p.eps, l16, cosr, sinr, kn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) knew.h[j] = f2bf(kn[j]);
         const int slot = p.slots ? p.slots[row] : -1;
         if (slot >= 0 && grp == 0 && (ctx - 1) >= t0 && (ctx - 1) < t0 + ATT2_SPLIT) {
-            Frag ko;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ko.h[j] = f2bf(knew[j]);
             const size_t off = ((size_t)slot * Hkv + kvh) * 128 + 8 * l16;
-            *reinterpret_cast<uint4 *>(p.kc + off) = ko.u;
-            *reinterpret_cast<uint4 *>(p.vc + off) = fv.u;
+            *reinterpret_cast<uint4 *>(p.kc + off) = knew.u;
+            *reinterpret_cast<uint4 *>(p.vc + off) = vnew.u;
         }
     }
 
+    // scores of the group's tokens, then one maximum, then the exponentials
+    const int rounds = min(TPG, (ctx - t0 + NG - 1) / NG);      // uniform: rounds that hold a token at all
+    float sc[TPG][G];
+#pragma unroll
+    for (int i = 0; i < TPG; ++i) {
+#pragma unroll
+        for (int h = 0; h < G; ++h) sc[i][h] = -INFINITY;
+        if (i >= rounds) continue;
+        const int t = t0 + i * NG + grp;
+        if (t == ctx - 1) {
+            kk[i].u = knew.u;
+            vv[i].u = vnew.u;
+        }
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += qf[h][j] * bf2f(kk[i].h[j]);
+            s = row16_sum(s) * p.scale;
+            sc[i][h] = t < ctx ? s : -INFINITY;
+        }
+    }
     float mx[G], ls[G], acc[G][8];
 #pragma unroll
     for (int h = 0; h < G; ++h) {
-        mx[h] = -INFINITY;
+        mx[h] = sc[0][h];
+#pragma unroll
+        for (int i = 1; i < TPG; ++i) mx[h] = fmaxf(mx[h], sc[i][h]);
         ls[h] = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
     }
-    for (int pass = 0; pass < 2; ++pass) {
-        const int base = t0 + pass * 128;
-        if (base >= ctx) break;
-        if (pass == 1) issue_loads(base);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (base + i * 16 >= ctx) break;          // uniform: no token left in this or later rounds
-            const int t = base + i * 16 + grp;
-            const bool valid = t < ctx;
-            const bool is_new = t == ctx - 1;
-            float kf[8], vf[8];
+    for (int i = 0; i < TPG; ++i) {
+        if (i >= rounds) continue;
+        float vf[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                kf[j] = is_new ? knew[j] : bf2f(kk[i].h[j]);
-                vf[j] = is_new ? vnew[j] : bf2f(vv[i].h[j]);
-            }
+        for (int j = 0; j < 8; ++j) vf[j] = bf2f(vv[i].h[j]);
 #pragma unroll
-            for (int h = 0; h < G; ++h) {
-                float s = 0.f;
+        for (int h = 0; h < G; ++h) {
+            // a masked score is -inf: its weight is 0 unless the whole group is empty (-inf - -inf), hence the test
+            const float pr = sc[i][h] == -INFINITY ? 0.f : __expf(sc[i][h] - mx[h]);
+            ls[h] += pr;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += qf[h][j] * kf[j];
-                s = row16_sum(s) * p.scale;
-                if (valid) {
-                    const float mn = fmaxf(mx[h], s);
-                    const float corr = __expf(mx[h] - mn);
-                    const float pr = __expf(s - mn);
-                    ls[h] = ls[h] * corr + pr;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[h][j] = acc[h][j] * corr + pr * vf[j];
-                    mx[h] = mn;
-                }
-            }
+            for (int j = 0; j < 8; ++j) acc[h][j] += pr * vf[j];
         }
     }
 #pragma unroll
@@ -900,40 +914,73 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const AttnFusedA
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < G * 128; e += 256) {
+    const bool direct = nact == 1;
+    for (int e = threadIdx.x; e < G * 128; e += NT) {
         const int h = e >> 7, d = e & 127;
         float M = -INFINITY;
 #pragma unroll
-        for (int gI = 0; gI < 16; ++gI) M = fmaxf(M, sm_m[gI][h]);
+        for (int gI = 0; gI < NG; ++gI) M = fmaxf(M, sm_m[gI][h]);
         float L = 0.f, o = 0.f;
-#pragma unroll
-        for (int gI = 0; gI < 16; ++gI) {
-            const float wgt = __expf(sm_m[gI][h] - M);
+#pragma unroll 8
+        for (int gI = 0; gI < NG; ++gI) {
+            const float wgt = __expf(sm_m[gI][h] - M);     // an empty group: exp(-inf) = 0
             L += sm_l[gI][h] * wgt;
             o += sm_acc[gI][h][d] * wgt;
         }
         const int hq = kvh * G + h;
-        if (p.nsplit == 1) {
+        if (direct) {
             p.out[(size_t)row * p.ldo + (size_t)hq * 128 + d] = f2bf(o / L);
         } else {
             const size_t pi = ((size_t)row * Hq + hq) * p.nsplit + split;
-            p.part_o[pi * 128 + d] = o;
+            st_agent(p.part_o + pi * 128 + d, o);
             if (d == 0) {
-                p.part_ml[pi * 2 + 0] = M;
-                p.part_ml[pi * 2 + 1] = L;
+                st_agent(p.part_ml + pi * 2 + 0, M);
+                st_agent(p.part_ml + pi * 2 + 1, L);
             }
         }
     }
+    if (direct) return;
+    // The last of the row's workgroups to arrive merges the partials.  Partials and counter are accessed
+    // with device-scope atomics only (they go to the level all XCDs share), the barrier waits for this
+    // workgroup's stores to be acknowledged before the counter moves, so no whole-cache write-back or
+    // invalidate is needed.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(p.counters + row * Hkv + kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sm_last = old == nact - 1;
+    }
+    __syncthreads();
+    if (!sm_last) return;
+    for (int e = threadIdx.x; e < G * 128; e += NT) {
+        const int h = e >> 7, d = e & 127;
+        const int hq = kvh * G + h;
+        const size_t p0 = ((size_t)row * Hq + hq) * p.nsplit;
+        float M = -INFINITY;
+        for (int s = 0; s < nact; ++s) M = fmaxf(M, ld_agent(p.part_ml + (p0 + s) * 2));
+        float L = 0.f, o = 0.f;
+        for (int s = 0; s < nact; ++s) {
+            const float wgt = __expf(ld_agent(p.part_ml + (p0 + s) * 2) - M);
+            L += ld_agent(p.part_ml + (p0 + s) * 2 + 1) * wgt;
+            o += ld_agent(p.part_o + (p0 + s) * 128 + d) * wgt;
+        }
+        p.out[(size_t)row * p.ldo + (size_t)hq * 128 + d] = f2bf(o / L);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(p.counters + row * Hkv + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 static inline int attn2_nsplit(int max_context) { return (max_context + ATT2_SPLIT - 1) / ATT2_SPLIT; }
+static inline size_t attn2_partial_bytes(int B, int Hq, int max_context) {
+    return ((size_t)B * Hq * attn2_nsplit(max_context) * (128 + 2) * sizeof(float) + 255) & ~(size_t)255;
+}
 
-extern "C" int qtts_attention_decode_fused(const void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w,
-                                           float eps, const void *rope_cos, const void *rope_sin, int max_pos,
-                                           const int64_t *positions, const int32_t *slot_mapping, void *k_cache,
-                                           void *v_cache, const int32_t *block_tables, int max_blocks,
-                                           const int32_t *context_lens, int max_context, float scale, void *out,
-                                           int ldo, int B, int Hq, int Hkv, void *workspace, qtts_stream_t stream) {
+static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w,
+                                       float eps, const void *rope_cos, const void *rope_sin, int max_pos,
+                                       const int64_t *positions, const int32_t *slot_mapping, void *k_cache,
+                                       void *v_cache, const int32_t *block_tables, int max_blocks,
+                                       const int32_t *context_lens, int max_context, float scale, void *out,
+                                       int ldo, int B, int Hq, int Hkv, void *partials, int *counters,
+                                       hipStream_t s) {
     QCHECK(qkv && q_norm_w && k_norm_w && rope_cos && rope_sin && positions && k_cache && v_cache && block_tables &&
                context_lens && out, "attention_decode_fused: null pointer");
     QCHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && ldqkv % 8 == 0 && ldqkv >= (Hq + 2 * Hkv) * 128 &&
@@ -941,28 +988,54 @@ extern "C" int qtts_attention_decode_fused(const void *qkv, int ldqkv, const voi
     QCHECK(max_pos > 0 && max_blocks > 0 && max_context > 0 && max_context <= max_blocks * QTTS_KV_BLOCK,
            "attention_decode_fused: bad context bounds");
     const int ns = attn2_nsplit(max_context);
-    QCHECK(ns == 1 || workspace, "attention_decode_fused: workspace required for contexts > %d", ATT2_SPLIT);
+    QCHECK(ns == 1 || (partials && counters), "attention_decode_fused: workspace required for contexts > %d", ATT2_SPLIT);
     AttnFusedArgs a;
     a.qkv = (const bf16_t *)qkv; a.ld = ldqkv; a.qw = (const bf16_t *)q_norm_w; a.kw = (const bf16_t *)k_norm_w; a.eps = eps;
     a.cosT = (const bf16_t *)rope_cos; a.sinT = (const bf16_t *)rope_sin; a.max_pos = max_pos; a.positions = positions; a.slots = slot_mapping;
     a.kc = (bf16_t *)k_cache; a.vc = (bf16_t *)v_cache; a.block_tables = block_tables; a.max_blocks = max_blocks;
     a.context_lens = context_lens; a.scale = scale; a.out = (bf16_t *)out; a.ldo = ldo; a.Hq = Hq; a.Hkv = Hkv;
-    a.part_o = (float *)workspace; a.part_ml = a.part_o ? a.part_o + (size_t)B * Hq * ns * 128 : nullptr; a.nsplit = ns;
+    a.part_o = (float *)partials; a.part_ml = a.part_o ? a.part_o + (size_t)B * Hq * ns * 128 : nullptr; a.nsplit = ns;
+    a.counters = counters;
     dim3 grid(B, Hkv, ns);
-    hipStream_t s = (hipStream_t)stream;
     switch (Hq / Hkv) {
-        case 1: hipLaunchKernelGGL((attn_decode_fused_kernel<1>), grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((attn_decode_fused_kernel<2>), grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<4>), grid, dim3(256), 0, s, a); break;
+        // short contexts (the code predictor's 17 tokens) leave most of a 32-group workgroup idle
+        case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 16>), grid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32>), grid, dim3(512), 0, s, a);
+                break;
+        case 2: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 16>), grid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((attn_decode_fused_kernel<2, 32>), grid, dim3(512), 0, s, a);
+                break;
+        case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<4, 16>), grid, dim3(256), 0, s, a); break;
         default: QFAIL(QTTS_EINVAL, "attention_decode_fused: unsupported q/kv head ratio %d", Hq / Hkv);
     }
     QLAUNCH();
-    if (ns > 1) {
-        hipLaunchKernelGGL(attn_combine_kernel, dim3(B, Hq), dim3(128), 0, s, a.part_o, a.part_ml, context_lens,
-                           (bf16_t *)out, ldo, Hq, ns, ATT2_SPLIT);
-        QLAUNCH();
-    }
     return QTTS_OK;
+}
+
+extern "C" size_t qtts_attn_decode_workspace_bytes(int B, int Hq, int Hkv, int max_context) {
+    if (B <= 0 || Hq <= 0 || Hkv <= 0 || max_context <= 0) return 0;
+    return attn2_partial_bytes(B, Hq, max_context) + (((size_t)B * Hkv * sizeof(int) + 255) & ~(size_t)255);
+}
+
+extern "C" int qtts_attention_decode_fused(const void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w,
+                                           float eps, const void *rope_cos, const void *rope_sin, int max_pos,
+                                           const int64_t *positions, const int32_t *slot_mapping, void *k_cache,
+                                           void *v_cache, const int32_t *block_tables, int max_blocks,
+                                           const int32_t *context_lens, int max_context, float scale, void *out,
+                                           int ldo, int B, int Hq, int Hkv, void *workspace, qtts_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int *counters = nullptr;
+    if (workspace && B > 0 && Hq > 0 && Hkv > 0 && max_context > 0) {
+        // the arrival counters sit behind the partials and must be zero when the kernel starts
+        counters = (int *)((char *)workspace + attn2_partial_bytes(B, Hq, max_context));
+        if (attn2_nsplit(max_context) > 1) {
+            hipError_t e = hipMemsetAsync(counters, 0, (size_t)B * Hkv * sizeof(int), s);
+            if (e != hipSuccess) QFAIL((int)e, "attention_decode_fused: memset failed: %s", hipGetErrorString(e));
+        }
+    }
+    return attention_decode_fused_impl(qkv, ldqkv, q_norm_w, k_norm_w, eps, rope_cos, rope_sin, max_pos, positions,
+                                       slot_mapping, k_cache, v_cache, block_tables, max_blocks, context_lens,
+                                       max_context, scale, out, ldo, B, Hq, Hkv, workspace, counters, s);
 }
 
 // ------------------------------------------------------------------ sampling
@@ -1332,7 +1405,7 @@ extern "C" int qtts_model_set_kv_cache(qtts_model_t *m, void *kv, int num_blocks
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t qkv, attn, act, xa, xb, att_ws, total;
+    size_t qkv, attn, act, xa, xb, att_ws, att_cnt, total;
 };
 
 static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
@@ -1344,7 +1417,11 @@ static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
     L.act = off; off += align256((size_t)rows * m->inter * 2);
     L.xa = off; off += align256((size_t)rows * m->hidden * 2);
     L.xb = off; off += align256((size_t)rows * m->hidden * 2);
-    L.att_ws = off; off += align256(qtts_attn_workspace_bytes(rows, m->n_heads, max_context));
+    // prefill and decode attention share the partials region; the decode kernel's arrival counters follow it
+    const size_t pre = qtts_attn_workspace_bytes(rows, m->n_heads, max_context);
+    const size_t dec = attn2_partial_bytes(rows, m->n_heads, max_context);
+    L.att_ws = off; off += align256(pre > dec ? pre : dec);
+    L.att_cnt = off; off += align256((size_t)rows * m->n_kv_heads * sizeof(int));
     L.total = off;
     return L;
 }
@@ -1359,6 +1436,10 @@ extern "C" int qtts_model_set_workspace(qtts_model_t *m, void *ws, size_t bytes,
     QCHECK(((uintptr_t)ws & 255) == 0, "model_set_workspace: workspace must be 256-byte aligned");
     QCHECK(bytes >= ws_layout(m, max_rows, max_context).total, "model_set_workspace: %zu bytes < required %zu", bytes,
            ws_layout(m, max_rows, max_context).total);
+    // the decode attention's arrival counters must start at zero (the kernel leaves them at zero)
+    const WsLayout W = ws_layout(m, max_rows, max_context);
+    hipError_t e = hipMemset((char *)ws + W.att_cnt, 0, W.total - W.att_cnt);
+    if (e != hipSuccess) QFAIL((int)e, "model_set_workspace: memset failed: %s", hipGetErrorString(e));
     m->ws = (char *)ws;
     m->ws_bytes = bytes;
     m->ws_rows = max_rows;
@@ -1399,10 +1480,10 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         if ((rc = qtts_linear_fused(cur, H, nullptr, 0, L.wqkv, nullptr, nullptr, 0, L.in_norm, m->eps, nullptr, 0, 0,
                                     qkv, qkvw, N, qkvw, H, stream))) return rc;
         if (decode) {
-            if ((rc = qtts_attention_decode_fused(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
+            if ((rc = attention_decode_fused_impl(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
                                                   positions, slot_mapping, kc, vc, block_tables, max_blocks,
                                                   context_lens, max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws,
-                                                  stream))) return rc;
+                                                  (int *)(m->ws + W.att_cnt), (hipStream_t)stream))) return rc;
         } else {
             if ((rc = qtts_qknorm_rope_store(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
                                              positions, slot_mapping, kc, vc, N, Hq, Hkv, stream))) return rc;

@@ -39,6 +39,7 @@ _SIGS = {
     "qtts_qknorm_rope_store": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "qtts_store_kvcache": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _p]),
     "qtts_attn_workspace_bytes": (_sz, [_i, _i, _i]),
+    "qtts_attn_decode_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "qtts_paged_attention": (_i, [_p, _i, _p, _p, _p, _i, _p, _p, _i, _f, _p, _i, _i, _i, _i, _p, _p]),
     "qtts_argmax": (_i, [_p, _i, _p, _i, _i, _p]),
     "qtts_sample_topk": (_i, [_p, _i, _p, _i, _u64, _u64, _p, _i, _i, _p]),

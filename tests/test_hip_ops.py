@@ -317,7 +317,8 @@ def test_attention_decode_fused(hip, Hq, Hkv, ctxs):
     kcd, vcd = kc.to(DEV), vc.to(DEV)
     out = torch.empty(B, Hq * 128, dtype=torch.bfloat16, device=DEV)
     maxc = max(max(ctxs), 1)
-    ws = torch.empty(hip.lib.qtts_attn_workspace_bytes(B, Hq, maxc), dtype=torch.uint8, device=DEV)
+    # scratch handed over dirty: the call itself clears the arrival counters it depends on
+    ws = torch.full((hip.lib.qtts_attn_decode_workspace_bytes(B, Hq, Hkv, maxc),), 0xAB, dtype=torch.uint8, device=DEV)
     qkvd, btd, cld = qkv.to(DEV), bt.to(DEV), cl.to(DEV)
     qwd, kwd, ctd, std, posd, slotsd = qw.to(DEV), kw.to(DEV), ct.to(DEV), st.to(DEV), pos.to(DEV), slots.to(DEV)   # keep alive
     hip.check(hip.lib.qtts_attention_decode_fused(hip.ptr(qkvd), qkvd.stride(0), hip.ptr(qwd), hip.ptr(kwd),
@@ -327,6 +328,16 @@ def test_attention_decode_fused(hip, Hq, Hkv, ctxs):
                                                   hip.ptr(ws), hip.stream()), "attention_decode_fused")
     torch.cuda.synchronize()
     assert torch.allclose(out.float().cpu().view(B, Hq, 128), want.float(), atol=1e-2, rtol=2e-2)
+    # a second launch over the same scratch (the new K/V rows are rewritten with the same values): same result
+    first = out.clone()
+    out.zero_()
+    hip.check(hip.lib.qtts_attention_decode_fused(hip.ptr(qkvd), qkvd.stride(0), hip.ptr(qwd), hip.ptr(kwd),
+                                                  1e-6, hip.ptr(ctd), hip.ptr(std), 2048, hip.ptr(posd),
+                                                  hip.ptr(slotsd), hip.ptr(kcd), hip.ptr(vcd), hip.ptr(btd), 4,
+                                                  hip.ptr(cld), maxc, 128 ** -0.5, hip.ptr(out), Hq * 128, B, Hq, Hkv,
+                                                  hip.ptr(ws), hip.stream()), "attention_decode_fused")
+    torch.cuda.synchronize()
+    assert torch.equal(out, first)
     # the cache received exactly the oracle's new K/V rows (K up to 1-ulp norm differences) and nothing else changed
     kdiff = (kcd.cpu().float() - kco.float()).abs()
     assert float(kdiff.max()) <= 0.0625 and float((kdiff > 0).float().mean()) < 1e-4
