@@ -24,7 +24,9 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
+    # kernel-argument preload: the first 16 dwords of a kernel's scalar arguments arrive in SGPRs with the wave
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-mllvm", "-amdgpu-kernarg-preload-count=16",
            "-I", os.path.join(ROOT, "include"), "-o", OUT] + SRC
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -162,8 +162,23 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 
 // EPI: 0 = bias/residual epilogue; 1 = SwiGLU: a tile's rows 0..7 are gate rows and rows 8..15 the up rows of the
 // same 8 outputs (qtts_pack_gate_up order), out[m][8*t + j] = bf16(bf16(silu(bf16 gate_j)) * bf16 up_j).
+// What the epilogue needs; everything the first loads depend on is passed as leading scalar arguments, which
+// the hardware can hand to a wave in registers at launch (kernel-argument preload) instead of through a
+// dependent scalar load.
+struct LinTail {
+    const bf16_t *bias, *res; int ldr;
+    bf16_t *xnorm_out; int ldxn;
+    bf16_t *out; int ldo;
+};
+
 template <int KSW, int PRO, bool DB, int EPI>
-__global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
+__global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uint4 *wp, const int64_t *ids,
+                                                      const bf16_t *nw, int ldx, int K, int N, int M, int tiles_per_wg,
+                                                      int id_rows, float eps, int dbg, const LinTail tl) {
+    LinArgs p;
+    p.x = x; p.ldx = ldx; p.ids = ids; p.id_rows = id_rows; p.wp = wp; p.bias = tl.bias; p.res = tl.res; p.ldr = tl.ldr;
+    p.nw = nw; p.eps = eps; p.xnorm_out = tl.xnorm_out; p.ldxn = tl.ldxn; p.out = tl.out; p.ldo = tl.ldo;
+    p.M = M; p.N = N; p.K = K; p.tiles_per_wg = tiles_per_wg; p.dbg = dbg;
     extern __shared__ float4_t smem4[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -338,7 +353,10 @@ __global__ __launch_bounds__(512) void linear2_kernel(const LinArgs p) {
 template <int KSW, int PRO, bool DB, int EPI>
 static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs &a) {
     size_t shmem = (size_t)2 * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
-    hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI>), grid, dim3(NW * 64), shmem, s, a);
+    LinTail tl;
+    tl.bias = a.bias; tl.res = a.res; tl.ldr = a.ldr; tl.xnorm_out = a.xnorm_out; tl.ldxn = a.ldxn; tl.out = a.out; tl.ldo = a.ldo;
+    hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids, a.nw, a.ldx,
+                       a.K, a.N, a.M, a.tiles_per_wg, a.id_rows, a.eps, a.dbg, tl);
 }
 
 static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = false) {
@@ -1524,6 +1542,40 @@ extern "C" int qtts_model_forward_logits(qtts_model_t *m, const void *x, const i
     QCHECK(head_w_packed && logits_out && vocab > 0 && vocab % 16 == 0, "model_forward_logits: bad head arguments");
     return model_forward_impl(m, x, positions, slot_mapping, row_seq, context_lens, block_tables, max_blocks, max_context,
                               N, hidden_out, head_w_packed, vocab, logits_out, stream);
+}
+
+// ------------------------------------------------------------------ grid barrier probe (tuning experiments only)
+// Every workgroup announces itself on one counter and waits until all have; `iters` rounds.  The wait is bounded:
+// a workgroup that never sees the others gives up, raises the flag behind the counter and leaves.
+__global__ __launch_bounds__(512) void grid_barrier_probe_kernel(int *bar, int iters) {
+    const int nwg = gridDim.x;
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int want = (it + 1) * nwg;
+            int spins = 0;
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                if (++spins > 2000000) {
+                    __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
+}
+
+extern "C" int qtts_debug_grid_barrier(int *bar2, int iters, int nwg, int threads, qtts_stream_t stream) {
+    QCHECK(bar2 && iters > 0 && nwg > 0 && nwg <= 256 && threads > 0 && threads <= 512, "grid barrier probe: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(bar2, 0, 2 * sizeof(int), s);
+    if (e != hipSuccess) QFAIL((int)e, "grid barrier probe: memset failed");
+    hipLaunchKernelGGL(grid_barrier_probe_kernel, dim3(nwg), dim3(threads), 0, s, bar2, iters);
+    QLAUNCH();
+    return QTTS_OK;
 }
 
 // ------------------------------------------------------------------ hipGraph helpers

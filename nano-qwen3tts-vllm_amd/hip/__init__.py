@@ -63,13 +63,14 @@ _SIGS = {
     "qtts_graph_destroy": (None, [_p]),
     "qtts_tune_linear": (None, [_i, _i]),
     "qtts_debug_linear": (None, [_i]),
+    "qtts_debug_grid_barrier": (_i, [_p, _i, _i, _i, _p]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)
     _fn.restype = _res
     _fn.argtypes = _args
 
-EXPORTED = [n for n in _SIGS if n not in ("qtts_tune_linear", "qtts_debug_linear")]
+EXPORTED = [n for n in _SIGS if n not in ("qtts_tune_linear", "qtts_debug_linear", "qtts_debug_grid_barrier")]
 
 
 class QttsError(RuntimeError):

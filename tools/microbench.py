@@ -167,6 +167,20 @@ def lat():
         print(line, flush=True)
 
 
+def gridbar():
+    """Cost of one device-wide barrier inside a resident kernel (all workgroups meet on one counter)."""
+    bar = torch.zeros(2, dtype=torch.int32, device=dev)
+    for nwg, threads in ((256, 512), (256, 64), (128, 512), (64, 512), (8, 512)):
+        res = []
+        for iters in (100, 1100):
+            def run():
+                hip.check(hip.lib.qtts_debug_grid_barrier(hip.ptr(bar), iters, nwg, threads, hip.stream()))
+            res.append(timed(run, 1))
+        torch.cuda.synchronize()
+        print(f"nwg {nwg:3d} x {threads:3d} threads: {(res[1] - res[0]) / 1000:6.2f} us per barrier   flag {int(bar[1])}  "
+              f"count {int(bar[0])}", flush=True)
+
+
 def dominant():
     """The dominant kernel of the path alone (talker RMSNorm + gate/up GEMM + SwiGLU launch, 1.7B shape, 8 rows),
     cycling through 28 weight buffers — the workload the PMC traffic passes are collected on."""
@@ -223,4 +237,4 @@ def frame():
 
 
 if __name__ == "__main__":
-    {"launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat}[sys.argv[1]]()
+    {"launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar}[sys.argv[1]]()
