@@ -17,7 +17,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = SRC + [os.path.join(ROOT, "include", "qtts_hip.h")]
+    deps = SRC + [os.path.join(HERE, "qtts_resident.inc"), os.path.join(ROOT, "include", "qtts_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <type_traits>
 #include <vector>
 
 #include "qtts_hip.h"
@@ -1545,38 +1546,73 @@ extern "C" int qtts_model_forward_logits(qtts_model_t *m, const void *x, const i
 }
 
 // ------------------------------------------------------------------ grid barrier probe (tuning experiments only)
-// Every workgroup announces itself on one counter and waits until all have; `iters` rounds.  The wait is bounded:
-// a workgroup that never sees the others gives up, raises the flag behind the counter and leaves.
-__global__ __launch_bounds__(512) void grid_barrier_probe_kernel(int *bar, int iters) {
-    const int nwg = gridDim.x;
+// `iters` device-wide barriers inside one resident kernel.  mode 0: every workgroup adds to one counter and polls
+// it.  mode 1: one arrival counter, the last arriver publishes the round number to per-group flags (256 B apart)
+// and a workgroup polls its group's flag only.  mode 2: arrival through per-group counters, the group's last
+// arriver adds to the top counter, flags as in mode 1.  Every wait is bounded: a workgroup that gives up raises
+// the error word and all leave.
+#define GB_STRIDE 64      // ints: one 256 B line per counter / flag
+__device__ __forceinline__ int gb_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gb_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int gb_add(int *p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(512) void grid_barrier_probe_kernel(int *mem, int iters, int mode, int gsize, int sleep) {
+    const int nwg = gridDim.x, wg = blockIdx.x;
+    const int ngroups = (nwg + gsize - 1) / gsize, grp = wg / gsize;
+    const int gmembers = min(gsize, nwg - grp * gsize);
+    int *err = mem, *top = mem + GB_STRIDE, *flags = mem + 2 * GB_STRIDE, *gcnt = mem + (2 + 64) * GB_STRIDE;
     for (int it = 0; it < iters; ++it) {
         __syncthreads();
         if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int want = (it + 1) * nwg;
+            const int round = it + 1;
+            const int *watch;
+            int want;
+            if (mode == 0) {
+                gb_add(top, 1);
+                watch = top;
+                want = round * nwg;
+            } else {
+                bool last;
+                if (mode == 1) {
+                    last = gb_add(top, 1) == round * nwg - 1;
+                } else {
+                    last = false;
+                    if (gb_add(gcnt + grp * GB_STRIDE, 1) == round * gmembers - 1)
+                        last = gb_add(top, 1) == round * ngroups - 1;
+                }
+                if (last)
+                    for (int g = 0; g < ngroups; ++g) gb_st(flags + g * GB_STRIDE, round);
+                watch = flags + grp * GB_STRIDE;
+                want = round;
+            }
             int spins = 0;
-            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            while (gb_ld(watch) < want) {
                 if (++spins > 2000000) {
-                    __hip_atomic_store(bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gb_st(err, 1);
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                if (sleep) __builtin_amdgcn_s_sleep(2);
             }
         }
         __syncthreads();
-        if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (gb_ld(err)) return;
     }
 }
 
-extern "C" int qtts_debug_grid_barrier(int *bar2, int iters, int nwg, int threads, qtts_stream_t stream) {
-    QCHECK(bar2 && iters > 0 && nwg > 0 && nwg <= 256 && threads > 0 && threads <= 512, "grid barrier probe: bad arguments");
+extern "C" int qtts_debug_grid_barrier(int *mem, int iters, int nwg, int threads, int mode, int gsize, int sleep,
+                                       qtts_stream_t stream) {
+    // mem: (2 + 64 + 64) * 256 bytes
+    QCHECK(mem && iters > 0 && nwg > 0 && nwg <= 256 && threads > 0 && threads <= 512 && gsize > 0 &&
+               (nwg + gsize - 1) / gsize <= 64, "grid barrier probe: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(bar2, 0, 2 * sizeof(int), s);
+    hipError_t e = hipMemsetAsync(mem, 0, (size_t)(2 + 64 + 64) * GB_STRIDE * sizeof(int), s);
     if (e != hipSuccess) QFAIL((int)e, "grid barrier probe: memset failed");
-    hipLaunchKernelGGL(grid_barrier_probe_kernel, dim3(nwg), dim3(threads), 0, s, bar2, iters);
+    hipLaunchKernelGGL(grid_barrier_probe_kernel, dim3(nwg), dim3(threads), 0, s, mem, iters, mode, gsize, sleep);
     QLAUNCH();
     return QTTS_OK;
 }
+
+#include "qtts_resident.inc"
 
 // ------------------------------------------------------------------ hipGraph helpers
 struct qtts_graph {

@@ -81,6 +81,7 @@ class FrameEngine:
         # nothing is stored, nothing advances) so that no code object is first loaded under capture.
         with self.tr.on_stream():
             self._setup_predictor_meta(1)
+            self.pr.prepare_resident(1)
             self._frame_body(1, 128)
             self._frame_body(1, 256)
             self.rng.zero_()
@@ -211,11 +212,13 @@ class FrameEngine:
 
     def _launch_frame(self, bs, max_ctx):
         if self.enforce_eager:
+            self.pr.prepare_resident(bs)
             self._frame_body(bs, max_ctx)
             return
         key = (bs, max_ctx)
         g = self.graphs.get(key)
         if g is None:
+            self.pr.prepare_resident(bs)          # uploads a stage table: not allowed while capturing
             g = self.graphs[key] = hip.Graph.capture(lambda: self._frame_body(bs, max_ctx))
         g.launch()
 

@@ -57,13 +57,17 @@ _SIGS = {
     "qtts_model_workspace_bytes": (_sz, [_p, _i, _i]),
     "qtts_model_set_workspace": (_i, [_p, _p, _sz, _i, _i]),
     "qtts_model_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "qtts_burst_program_bytes": (_sz, [_p, _i, _i]),
+    "qtts_burst_build": (_i, [_p, _p, _sz, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p]),
+    "qtts_burst_launch": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _i, _u64, _p, _i, _p]),
+    "qtts_burst_status": (_i, [_p, _p, _i, _i]),
     "qtts_graph_begin": (_i, [_p]),
     "qtts_graph_end": (_p, [_p]),
     "qtts_graph_launch": (_i, [_p, _p]),
     "qtts_graph_destroy": (None, [_p]),
     "qtts_tune_linear": (None, [_i, _i]),
     "qtts_debug_linear": (None, [_i]),
-    "qtts_debug_grid_barrier": (_i, [_p, _i, _i, _i, _p]),
+    "qtts_debug_grid_barrier": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)

@@ -81,10 +81,13 @@ def test_talker_engine_matches_reference_fixture(setup, eager):
     llm.exit()
 
 
-@pytest.mark.parametrize("burst", ["1", "0"])
-def test_predictor_engine_burst_matches_reference_fixture(setup, burst, monkeypatch):
+@pytest.mark.parametrize("burst,resident", [("1", "1"), ("1", "0"), ("0", "0")])
+def test_predictor_engine_burst_matches_reference_fixture(setup, burst, resident, monkeypatch):
+    """burst=1/resident=1: the whole burst as one resident kernel; burst=1/resident=0: one graph of per-stage
+    launches; burst=0: one engine step per token (the reference's contract)."""
     from nano_qwen3tts_vllm.llm import PredictorLLM
     monkeypatch.setenv("QTTS_PREDICTOR_BURST", burst)
+    monkeypatch.setenv("QTTS_PREDICTOR_RESIDENT", resident)
     d, cfg, tw, pw, g = setup
     llm = PredictorLLM(d, enforce_eager=False, num_kvcache_blocks=4, max_num_seqs=16, max_num_batched_tokens=1024)
     pin = torch.from_numpy(g["p_in"])
@@ -110,7 +113,51 @@ def test_predictor_engine_burst_matches_reference_fixture(setup, burst, monkeypa
                 break                        # near-tie in the reference's own logits: later ids may differ
             assert got[t] == int(want[i, t]), f"seq {i} step {t}: {got[t]} != {want[i, t]} (margin {margin[i, t]})"
     assert len(llm.scheduler.block_manager.free_block_ids) == 4
+    mr = llm.model_runner
+    assert bool(mr._programs) == (burst == "1" and resident == "1")
+    for bs in mr._programs:
+        assert mr.resident_status(bs) == 0, "a workgroup gave up at a barrier"
     llm.exit()
+
+
+@pytest.mark.parametrize("wgs,group", [(256, 16), (64, 64)])
+def test_resident_burst_equals_staged_burst_at_model_shapes(wgs, group, monkeypatch, tmp_path):
+    """1.7B predictor shapes, 8 sequences: the resident kernel and the graph of per-stage launches run the same
+    arithmetic, so with well separated logits (head weights scaled up) they must pick the same 15 ids."""
+    import json, os
+    from nano_qwen3tts_vllm.engine.model_runner.predictor_model_runner import PredictorSequence
+    from nano_qwen3tts_vllm.llm import PredictorLLM
+    cfg = synthetic.make_config("1.7B")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    pw = {}
+    for k, shp in synthetic.checkpoint_shapes(cfg).items():
+        if not k.startswith("talker.code_predictor."):
+            continue
+        if k.endswith("norm.weight") or k.endswith("layernorm.weight"):
+            w = torch.ones(shp, dtype=torch.bfloat16, device="cuda")
+        else:
+            std = 0.05 if "codec_embedding" in k else (0.8 if "lm_head" in k else 0.02)
+            w = (torch.randn(shp, generator=gen, device="cuda") * std).to(torch.bfloat16)
+        pw[k[len("talker.code_predictor."):]] = w
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(3)
+    pin = (torch.randn(8, 2, cfg["talker_config"]["hidden_size"], generator=gen) * 0.5).bfloat16()
+    results = {}
+    for resident in ("1", "0"):
+        monkeypatch.setenv("QTTS_PREDICTOR_RESIDENT", resident)
+        monkeypatch.setenv("QTTS_RESIDENT_WGS", str(wgs))
+        monkeypatch.setenv("QTTS_RESIDENT_GROUP", str(group))
+        llm = PredictorLLM(str(tmp_path), weights=pw, num_kvcache_blocks=8, max_num_seqs=8, max_num_batched_tokens=1024)
+        for i in range(8):
+            llm.add_request([pin[i].unsqueeze(0)], greedy_sp(17), request_id=f"p{i}")
+        outs, _ = llm.step()
+        results[resident] = {rid: toks for rid, _sid, toks in outs}
+        for bs in llm.model_runner._programs:
+            assert llm.model_runner.resident_status(bs) == 0
+        assert bool(llm.model_runner._programs) == (resident == "1")
+        llm.exit()
+    same = sum(results["1"][f"p{i}"] == results["0"][f"p{i}"] for i in range(8))
+    assert same >= 7, (results["1"], results["0"])
 
 
 def test_frame_loop_ids_match_reference_fixture(setup):

@@ -168,17 +168,19 @@ def lat():
 
 
 def gridbar():
-    """Cost of one device-wide barrier inside a resident kernel (all workgroups meet on one counter)."""
-    bar = torch.zeros(2, dtype=torch.int32, device=dev)
-    for nwg, threads in ((256, 512), (256, 64), (128, 512), (64, 512), (8, 512)):
-        res = []
-        for iters in (100, 1100):
-            def run():
-                hip.check(hip.lib.qtts_debug_grid_barrier(hip.ptr(bar), iters, nwg, threads, hip.stream()))
-            res.append(timed(run, 1))
-        torch.cuda.synchronize()
-        print(f"nwg {nwg:3d} x {threads:3d} threads: {(res[1] - res[0]) / 1000:6.2f} us per barrier   flag {int(bar[1])}  "
-              f"count {int(bar[0])}", flush=True)
+    """Cost of one device-wide barrier inside a resident kernel, for a few barrier shapes."""
+    mem = torch.zeros((2 + 64 + 64) * 64, dtype=torch.int32, device=dev)
+    for mode, gsize, sleep in ((0, 32, 1), (0, 32, 0), (1, 8, 1), (1, 8, 0), (1, 16, 0), (1, 32, 0), (2, 8, 0), (2, 16, 0), (2, 16, 1)):
+        line = f"mode {mode} group {gsize:2d} sleep {sleep}:"
+        for nwg in (256, 128, 64):
+            res = []
+            for iters in (100, 1100):
+                def run():
+                    hip.check(hip.lib.qtts_debug_grid_barrier(hip.ptr(mem), iters, nwg, 512, mode, gsize, sleep, hip.stream()))
+                res.append(timed(run, 1))
+            torch.cuda.synchronize()
+            line += f"  nwg {nwg:3d}: {(res[1] - res[0]) / 1000:5.2f} us (err {int(mem[0])})"
+        print(line, flush=True)
 
 
 def dominant():
@@ -227,8 +229,11 @@ def frame():
     def burst_body():
         pr._burst_body(B)
 
+    only = os.environ.get("QTTS_FRAME_ONLY")
     for name, body, nk in (("talker 28 layers", talker_body, 1), ("predictor burst", burst_body, 1),
                            ("whole frame", lambda: fe._frame_body(B, 256), 1)):
+        if only and only not in name:
+            continue
         with torch.cuda.stream(tr.stream):
             body()
             g = hip.Graph.capture(body)
