@@ -100,8 +100,18 @@ class Qwen3TTSInterface:
         self._zmq_tasks: list[asyncio.Task] = []
         self._zmq_tasks_started = False
         self._frame_engine = None
+        # generate_async is served either by the two worker loops of the reference's design ("workers") or by one
+        # in-process loop over the frame engine, which keeps hidden states and ids on the device between the
+        # talker and the predictor ("fused", the default)
+        self._async_engine = os.environ.get("QTTS_ASYNC_ENGINE", "fused")
+        self._fused_task: asyncio.Task | None = None
+        self._fused_pending: list = []
+        self._fused_cancelled: list = []
+        self._fused_wake: asyncio.Event | None = None
+        self.max_streams = int(os.environ.get("QTTS_MAX_STREAMS", "8"))
         self.do_sample = True            # the reference always samples (T=1.0 talker, T=0.9 predictor, top-k 50)
         self.max_frames = 1024           # explicit stop: the reference has no length guard (ends only on codec EOS)
+        self.ignore_eos = False          # benchmarks with random weights: keep generating through codec id 2150
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, *, cache_dir=None, force_download=False,
@@ -132,6 +142,11 @@ class Qwen3TTSInterface:
         if self._zmq_tasks_started:
             return
         self._zmq_tasks_started = True
+        if self._async_engine == "fused":
+            self._engine(self.max_streams)
+            self._fused_wake = asyncio.Event()
+            self._fused_task = asyncio.create_task(self._run_fused_loop())
+            return
         from .workers.client_bridge import start_multiprocess_engines
         from .zmq.engine_loop_mp import run_predictor_loop_mp, run_talker_loop_mp
         holder = start_multiprocess_engines(self.model_path, self._request_queues, self._queues_lock,
@@ -147,6 +162,14 @@ class Qwen3TTSInterface:
         await asyncio.sleep(0.05)
 
     async def stop_zmq_tasks(self) -> None:
+        if self._fused_task is not None:
+            self._fused_task.cancel()
+            await asyncio.gather(self._fused_task, return_exceptions=True)
+            self._fused_task = None
+            for q in self._request_queues.values():
+                q.put_nowait(None)
+            self._zmq_tasks_started = False
+            return
         if not self._zmq_tasks:
             return
         for t in self._zmq_tasks:
@@ -168,10 +191,90 @@ class Qwen3TTSInterface:
             return nxt + trailing_text_hiddens[:, step].unsqueeze(1)
         return nxt + tts_pad_embed
 
+    # ---------------------------------------------------------------- async path (one loop over the frame engine)
+    async def _run_fused_loop(self) -> None:
+        """Continuous batching over the frame engine: between two frames, streams whose consumer went away are
+        dropped and waiting requests are admitted (their prefill runs there); every frame goes to its
+        request's queue, `None` ends a stream (codec EOS, frame budget, or no free row / KV block)."""
+        fe = self._frame_engine
+        budget: dict[str, int] = {}
+        while True:
+            for rid in self._fused_cancelled:
+                fe.remove_stream(rid)
+                budget.pop(rid, None)
+            self._fused_cancelled.clear()
+            still_waiting = []
+            for req in self._fused_pending:
+                rid, prompt, text_adds, n, tsp, psp = req
+                if len(fe.streams) >= fe.max_streams:
+                    still_waiting.append(req)
+                    continue
+                try:
+                    fe.add_stream(prompt, text_adds, max_frames=n, talker_sampling=tsp, predictor_sampling=psp, sid=rid)
+                    budget[rid] = n
+                except AssertionError as e:                       # does not fit (length / KV blocks): end it
+                    logger.warning(f"[fused_loop] request {rid[:8]} rejected: {e}")
+                    q = self._request_queues.get(rid)
+                    if q is not None:
+                        q.put_nowait(None)
+            self._fused_pending[:] = still_waiting
+            if not fe.streams:
+                self._fused_wake.clear()
+                if not self._fused_pending:
+                    await self._fused_wake.wait()
+                continue
+            active = list(fe.streams)
+            res = fe.step()
+            for rid in active:
+                q = self._request_queues.get(rid)
+                frame = res.get(rid)
+                if frame is not None and q is not None:
+                    q.put_nowait(frame)
+                    budget[rid] -= 1
+                if frame is None or budget.get(rid, 0) <= 0:
+                    fe.remove_stream(rid)
+                    budget.pop(rid, None)
+                    if q is not None:
+                        q.put_nowait(None)
+            await asyncio.sleep(0)                                # consumers and new requests run between frames
+
+    async def _generate_async_fused(self, inputs_embeds, trailing_text_hiddens, tts_pad_embed, request_id):
+        fe = self._frame_engine
+        prompt = inputs_embeds.reshape(-1, inputs_embeds.shape[-1])
+        n = min(self.max_frames, fe.tr.config.max_model_len - prompt.shape[0] - 2)
+        text = trailing_text_hiddens.reshape(-1, trailing_text_hiddens.shape[-1]).float()
+        pad = tts_pad_embed.reshape(1, -1).float().to(text.device)
+        text_adds = torch.cat([text, pad], 0)
+        tsp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=self.do_sample)
+        psp = SamplingParams(temperature=0.9, max_tokens=17, do_sample=self.do_sample)
+        q: asyncio.Queue = asyncio.Queue()
+        async with self._queues_lock:
+            self._request_queues[request_id] = q
+        self._fused_pending.append((request_id, prompt, text_adds, n, tsp, psp))
+        self._fused_wake.set()
+        try:
+            while True:
+                frame = await q.get()
+                if frame is None:
+                    return
+                yield frame
+        finally:
+            async with self._queues_lock:
+                self._request_queues.pop(request_id, None)
+            self._fused_pending[:] = [r for r in self._fused_pending if r[0] != request_id]
+            if request_id in fe.streams:
+                self._fused_cancelled.append(request_id)
+                self._fused_wake.set()
+
     async def generate_async(self, inputs_embeds: torch.Tensor, trailing_text_hiddens: torch.Tensor,
                              tts_pad_embed: torch.Tensor, talker_attention_mask: torch.Tensor | None = None,
                              request_id: str | None = None):
         """Async generator of 16-id frames.  `await start_zmq_tasks()` first."""
+        if self._fused_task is not None:
+            async for frame in self._generate_async_fused(inputs_embeds, trailing_text_hiddens, tts_pad_embed,
+                                                          request_id or str(uuid.uuid4())):
+                yield frame
+            return
         if not (self._use_mp_engines and self._mp_holder is not None):
             raise RuntimeError("generate_async requires start_zmq_tasks() to be called first")
         tsp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=self.do_sample)
@@ -194,7 +297,7 @@ class Qwen3TTSInterface:
                 if not (engine_type == "talker" and msg_type == "token"):
                     continue
                 last_id = payload["token_ids"][-1]
-                if last_id == CODEC_EOS:
+                if last_id == CODEC_EOS and not self.ignore_eos:
                     break
                 last_id_hidden = self.input_embedding(torch.tensor([last_id], device=self.device)).unsqueeze(0)
                 h = torch.as_tensor(payload["hidden_states"]).to(self.device).float().reshape(1, 1, -1)
@@ -220,7 +323,7 @@ class Qwen3TTSInterface:
             from .engine.frame_engine import FrameEngine
             self._frame_engine = FrameEngine(self.model_path, max_streams=max_streams, enforce_eager=self._enforce_eager,
                                              gpu_memory_utilization=self._gpu_memory_utilization / 2.0,
-                                             codec_eos=CODEC_EOS)
+                                             codec_eos=None if self.ignore_eos else CODEC_EOS)
         return self._frame_engine
 
     def generate(self, inputs_embeds: torch.Tensor, trailing_text_hiddens: torch.Tensor, tts_pad_embed: torch.Tensor,

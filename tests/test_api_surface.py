@@ -164,6 +164,7 @@ def test_interface_generate_async_with_inprocess_clients(model_dir, monkeypatch)
     import nano_qwen3tts_vllm.llm as llm
     from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
     monkeypatch.setenv("QTTS_INPROCESS", "1")
+    monkeypatch.setenv("QTTS_ASYNC_ENGINE", "workers")     # the reference's two-engine orchestration (the fused loop needs a GPU)
     monkeypatch.setattr(llm, "TalkerLLM", FakeTalker)
     monkeypatch.setattr(llm, "PredictorLLM", FakePredictor)
     iface = Qwen3TTSInterface.from_pretrained(model_dir)

@@ -39,9 +39,13 @@ def check(got, want, margins):
             return
 
 
-def test_generate_async_matches_fixture(model, monkeypatch):
+@pytest.mark.parametrize("mode", ["fused", "workers"])
+def test_generate_async_matches_fixture(model, monkeypatch, mode):
+    """fused: one loop over the device-resident frame engine; workers: the reference's talker / predictor
+    loops over the two engines (in-process clients)."""
     from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
     monkeypatch.setenv("QTTS_INPROCESS", "1")
+    monkeypatch.setenv("QTTS_ASYNC_ENGINE", mode)
     d, prompts, text, want, margins = model
     iface = Qwen3TTSInterface.from_pretrained(d, gpu_memory_utilization=0.05)
     iface.do_sample = False
@@ -62,6 +66,57 @@ def test_generate_async_matches_fixture(model, monkeypatch):
     for i in range(2):
         assert len(res[i]) == 6 and all(len(f) == 16 for f in res[i])
         check(res[i], want[i], margins[i])
+    iface.shutdown()
+
+
+def test_fused_async_continuous_batching(model, monkeypatch):
+    """More requests than rows, a consumer that leaves early, staggered arrival: every stream still gets its
+    own frames, and rows / KV blocks are all returned."""
+    from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
+    monkeypatch.setenv("QTTS_ASYNC_ENGINE", "fused")
+    monkeypatch.setenv("QTTS_MAX_STREAMS", "2")
+    d, prompts, text, want, margins = model
+    iface = Qwen3TTSInterface.from_pretrained(d, gpu_memory_utilization=0.05)
+    iface.do_sample = False
+    iface.max_frames = 6
+    pad = torch.zeros(1, 1, prompts[0].shape[-1])
+
+    async def run():
+        await iface.start_zmq_tasks()
+
+        async def one(i, delay):
+            await asyncio.sleep(delay)
+            return [f async for f in iface.generate_async(prompts[i].unsqueeze(0), text[i].unsqueeze(0), pad, None)]
+
+        async def early():
+            agen = iface.generate_async(prompts[0].unsqueeze(0), text[0].unsqueeze(0), pad, None, request_id="early")
+            first = await agen.__anext__()
+            await agen.aclose()
+            return first
+        res = await asyncio.gather(one(0, 0), one(1, 0), one(0, 0.002), one(1, 0.01), early())
+        await asyncio.sleep(0.01)
+        fe = iface._frame_engine
+        state = (len(fe.streams), len(fe.talker.scheduler.block_manager.free_block_ids), dict(iface._request_queues))
+        await iface.stop_zmq_tasks()
+        return res, state
+
+    res, (n_streams, free_blocks, queues) = asyncio.run(run())
+    for got, i in zip(res[:4], (0, 1, 0, 1)):
+        assert len(got) == 6
+        check(got, want[i], margins[i])
+    assert list(res[4]) == list(res[0][0])
+    assert n_streams == 0 and not queues
+    iface.shutdown()
+    assert free_blocks == iface_free_blocks_total(d)
+
+
+def iface_free_blocks_total(d):
+    """Blocks a fresh frame engine of the same configuration starts with."""
+    from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
+    iface = Qwen3TTSInterface.from_pretrained(d, gpu_memory_utilization=0.05)
+    n = len(iface._engine(2).talker.scheduler.block_manager.free_block_ids)
+    iface.shutdown()
+    return n
 
 
 def test_sync_generate_matches_fixture(model):
