@@ -30,6 +30,10 @@ from .sequence import Sequence
 CODEC_EOS = 2150        # hard-coded in the reference's API loop (P/interface.py:1233)
 
 
+class NoCapacity(RuntimeError):
+    """No free row or not enough free KV blocks right now; the request can be admitted later."""
+
+
 class Stream:
     def __init__(self, sid, row, seq, n_text):
         self.sid, self.row, self.seq, self.n_text = sid, row, seq, n_text
@@ -93,7 +97,9 @@ class FrameEngine:
                    sid: str | None = None) -> str:
         """prompt_embeds [L,H]; text_adds fp32 [F,H]: what the API adds to the codec-embedding sum at
         frame f (trailing text hiddens, then the tts pad embedding; the last row repeats)."""
-        row = next(i for i, s in enumerate(self.rows) if s is None)
+        row = next((i for i, s in enumerate(self.rows) if s is None), None)
+        if row is None:
+            raise NoCapacity("all stream rows are taken")
         sid = sid or f"stream-{self._next_sid}"
         self._next_sid += 1
         tsp = talker_sampling or SamplingParams(temperature=1.0, max_tokens=1)
@@ -104,7 +110,8 @@ class FrameEngine:
         seq = Sequence([], input_embeds=prompt_embeds.reshape(1, L, -1), sampling_params=tsp, request_id=sid)
         bm = self.talker.scheduler.block_manager
         need = (total + 255) // 256
-        assert len(bm.free_block_ids) >= need, "out of KV blocks"
+        if len(bm.free_block_ids) < need:
+            raise NoCapacity(f"{need} KV blocks needed, {len(bm.free_block_ids)} free")
         seq.block_table = [bm._take() for _ in range(need)]
         with self.tr.on_stream():
             toks, hidden = self.tr._run([seq], True)          # prefill (eager path of the runner)

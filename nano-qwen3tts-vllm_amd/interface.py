@@ -196,6 +196,7 @@ class Qwen3TTSInterface:
         """Continuous batching over the frame engine: between two frames, streams whose consumer went away are
         dropped and waiting requests are admitted (their prefill runs there); every frame goes to its
         request's queue, `None` ends a stream (codec EOS, frame budget, or no free row / KV block)."""
+        from .engine.frame_engine import NoCapacity
         fe = self._frame_engine
         budget: dict[str, int] = {}
         while True:
@@ -212,11 +213,18 @@ class Qwen3TTSInterface:
                 try:
                     fe.add_stream(prompt, text_adds, max_frames=n, talker_sampling=tsp, predictor_sampling=psp, sid=rid)
                     budget[rid] = n
-                except AssertionError as e:                       # does not fit (length / KV blocks): end it
-                    logger.warning(f"[fused_loop] request {rid[:8]} rejected: {e}")
-                    q = self._request_queues.get(rid)
-                    if q is not None:
-                        q.put_nowait(None)
+                    continue
+                except NoCapacity as e:
+                    if fe.streams:                                # blocks come back when a running stream ends
+                        still_waiting.append(req)
+                        continue
+                    reason = e
+                except AssertionError as e:                       # can never fit (prompt + frames > max_model_len)
+                    reason = e
+                logger.warning(f"[fused_loop] request {rid[:8]} rejected: {reason}")
+                q = self._request_queues.get(rid)
+                if q is not None:
+                    q.put_nowait(None)
             self._fused_pending[:] = still_waiting
             if not fe.streams:
                 self._fused_wake.clear()

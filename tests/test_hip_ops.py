@@ -347,3 +347,63 @@ def test_attention_decode_fused(hip, Hq, Hkv, ctxs):
     kdiff = (kcd.cpu().float() - kco.float()).abs()
     assert float(kdiff.max()) <= 0.0625 and float((kdiff > 0).float().mean()) < 1e-4
     assert torch.equal(vcd.cpu(), vco)
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(17, 256, 128, "norm"), (40, 4096, 2048, "norm"), (200, 2048, 2048, "res"),
+                                        (200, 2048, 6144, "res"), (130, 1024, 3072, "bias"), (200, 6144, 1024, "swiglu"),
+                                        (33, 3072, 2048, "head")])
+def test_linear_prefill_row_counts(hip, M, N, K, kind):
+    """Prefill-sized row counts (several 16-row tiles, ragged last tile) through every GEMM variant of the
+    decoder stack, against the oracle."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().to(DEV)
+    res = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g).bfloat16().to(DEV)
+    xd = x.to(DEV)
+
+    def run():
+        if kind == "swiglu":
+            wg = (torch.randn(N // 2, K, generator=torch.Generator().manual_seed(1)) * 0.05).bfloat16()
+            wu = (torch.randn(N // 2, K, generator=torch.Generator().manual_seed(2)) * 0.05).bfloat16()
+            return hip.linear_swiglu(xd, hip.pack_gate_up(wg.to(DEV), wu.to(DEV)), N // 2, norm_w=nw), (wg, wu)
+        w = (torch.randn(N, K, generator=torch.Generator().manual_seed(3)) * 0.05).bfloat16()
+        wp = hip.pack_weight(w.to(DEV))
+        if kind == "norm":
+            return hip.linear(xd, wp, N, norm_w=nw), w
+        if kind == "head":
+            xn = torch.zeros(M, K, dtype=torch.bfloat16, device=DEV)
+            out = hip.linear_fused(xd, wp, N, norm_w=nw, xnorm_out=xn)
+            return torch.cat([out, xn], 1), w
+        if kind == "res":
+            return hip.linear(xd, wp, N, residual=res), w
+        return hip.linear(xd, wp, N, bias=bias, residual=res), w
+
+    got, w = run()
+    xf = x
+    if kind in ("norm", "head", "swiglu"):
+        xf = O.rms_norm(x, nw.cpu(), 1e-6)
+    if kind == "swiglu":
+        want = O.silu_mul(torch.nn.functional.linear(xf, w[0]), torch.nn.functional.linear(xf, w[1])).float()
+        diff = (got.float().cpu() - want).abs()
+        # two chained roundings: a 1-ulp flip of gate or up moves the product by about 2 ulp; for gates
+        # around -2..-6 silu amplifies the relative error of the rounded gate up to 3x, hence the rare tail
+        assert float((diff > want.abs() * 2.0 ** -6 + 1e-6).float().mean()) < 1e-3
+        assert float((diff > want.abs() * 2.0 ** -4 + 1e-6).float().mean()) == 0.0
+        assert float((diff > 0).float().mean()) < 0.03
+        return
+    elif kind == "head":
+        want = torch.cat([torch.nn.functional.linear(xf, w), xf], 1)
+    else:
+        want = torch.nn.functional.linear(xf, w, bias.cpu() if kind == "bias" else None)
+        if kind in ("res", "bias"):
+            # the rounding that may differ by one ulp happens before the residual add, at the GEMM output's
+            # magnitude: compare there (the add itself is exact to its own rounding in both)
+            lin = want.float()
+            want = want + res.cpu()
+            diff = (got.float().cpu() - want.float()).abs()
+            ulp = (lin.abs() + want.float().abs()) * 2.0 ** -7 * 1.01 + 1e-5     # one ulp at each of the two roundings
+            assert not (diff > ulp).any(), f"rows {kind}: max diff {float(diff.max())}"
+            assert float((diff > 0).float().mean()) <= 0.02
+            return
+    assert_bf16_close(got, want, what=f"rows {kind}")
