@@ -159,12 +159,21 @@ def main():
 
     rank, world, local = dist_env()
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    # Rehearsal on a box with fewer GPUs than ranks (QTTS_BENCH_REHEARSAL=1): every rank uses GPU 0 and the
+    # timing collectives run over gloo, since RCCL refuses two ranks on one device.  Never used for reported numbers.
+    rehearsal = os.environ.get("QTTS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    coll_device = None if rehearsal else device
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
     from nano_qwen3tts_vllm.sampling_params import SamplingParams
@@ -212,7 +221,7 @@ def main():
     fe.run_frames(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, world, device)
+    elapsed = max_over_ranks(elapsed, world, coll_device)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -228,7 +237,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Qwen3-TTS-12Hz-{args.size} shapes, {B} concurrent streams per GPU, greedy, "
                                    f"continuous decode with one hipGraph per frame; prompts {prompt_lens} tokens, "
-                                   f"random-init weights", "streams_per_gpu": B, "replicas": world},
+                                   f"random-init weights" + (" [REHEARSAL: all ranks on one GPU]" if rehearsal else ""),
+                       "streams_per_gpu": B, "replicas": world},
             "rtf": ms_per_step * 1e-3 / FRAME_SECONDS,
             "first_chunk_ms_p50": statistics.median(first_frame_ms) + frame0_ms,
             "prefill_ms": first_frame_ms,

@@ -351,7 +351,8 @@ def test_attention_decode_fused(hip, Hq, Hkv, ctxs):
 
 @pytest.mark.parametrize("M,N,K,kind", [(17, 256, 128, "norm"), (40, 4096, 2048, "norm"), (200, 2048, 2048, "res"),
                                         (200, 2048, 6144, "res"), (130, 1024, 3072, "bias"), (200, 6144, 1024, "swiglu"),
-                                        (33, 3072, 2048, "head")])
+                                        (33, 3072, 2048, "head"), (200, 6144, 1024, "swiglu_plain"), (40, 12288, 2048, "swiglu_plain"),
+                                        (250, 4096, 2048, "plain"), (300, 512, 256, "plain"), (24, 256, 128, "res")])
 def test_linear_prefill_row_counts(hip, M, N, K, kind):
     """Prefill-sized row counts (several 16-row tiles, ragged last tile) through every GEMM variant of the
     decoder stack, against the oracle."""
@@ -363,12 +364,15 @@ def test_linear_prefill_row_counts(hip, M, N, K, kind):
     xd = x.to(DEV)
 
     def run():
-        if kind == "swiglu":
+        if kind.startswith("swiglu"):
             wg = (torch.randn(N // 2, K, generator=torch.Generator().manual_seed(1)) * 0.05).bfloat16()
             wu = (torch.randn(N // 2, K, generator=torch.Generator().manual_seed(2)) * 0.05).bfloat16()
-            return hip.linear_swiglu(xd, hip.pack_gate_up(wg.to(DEV), wu.to(DEV)), N // 2, norm_w=nw), (wg, wu)
+            return hip.linear_swiglu(xd, hip.pack_gate_up(wg.to(DEV), wu.to(DEV)), N // 2,
+                                     norm_w=nw if kind == "swiglu" else None), (wg, wu)
         w = (torch.randn(N, K, generator=torch.Generator().manual_seed(3)) * 0.05).bfloat16()
         wp = hip.pack_weight(w.to(DEV))
+        if kind == "plain":
+            return hip.linear(xd, wp, N), w
         if kind == "norm":
             return hip.linear(xd, wp, N, norm_w=nw), w
         if kind == "head":
@@ -383,7 +387,7 @@ def test_linear_prefill_row_counts(hip, M, N, K, kind):
     xf = x
     if kind in ("norm", "head", "swiglu"):
         xf = O.rms_norm(x, nw.cpu(), 1e-6)
-    if kind == "swiglu":
+    if kind.startswith("swiglu"):
         want = O.silu_mul(torch.nn.functional.linear(xf, w[0]), torch.nn.functional.linear(xf, w[1])).float()
         diff = (got.float().cpu() - want).abs()
         # two chained roundings: a 1-ulp flip of gate or up moves the product by about 2 ulp; for gates
