@@ -1,17 +1,21 @@
 """One request at a time through the API object: the counterpart of the reference's examples/quick_benchmark.py
-(E/quick_benchmark.py:25-84: from_pretrained -> warm-up -> N timed generations -> audio seconds from the frame
-count -> average time and RTF) for the decode path.  The reference starts from text; turning text into input
-embeddings is outside this build, so requests are synthetic embeddings of the same shapes, and the codec
-decode (codes -> PCM) is not timed.
+(E/quick_benchmark.py:25-84: from_pretrained -> warm-up -> N timed generate_voice_design(text, instruct) calls ->
+audio seconds from the frame count -> average time and RTF).  Text goes in as there; on an offline box the
+released tokenizer is replaced by a character-level stand-in and the weights are random, so the audio is
+noise and generation runs to a fixed frame count instead of the codec's end token.  The codec decode
+(codes -> PCM) is not part of this build and is not timed.
 
-    python examples/quick_benchmark.py [--size 1.7B] [--runs 3] [--frames 125] [--prompt-len 48] [--sample]
+    python examples/quick_benchmark.py [--size 1.7B] [--runs 3] [--frames 125] [--sample] [--embeds]
 """
 import argparse
 import json
 import statistics
 import time
 
-from _common import FRAME_SECONDS, model_dir, request
+from _common import FRAME_SECONDS, CharProcessor, model_dir, request
+
+TEXT = "The quick brown fox jumps over the lazy dog while the evening train rolls slowly out of the station."
+INSTRUCT = "A warm, unhurried male voice in his forties, speaking clearly."
 
 
 def main():
@@ -22,6 +26,7 @@ def main():
     ap.add_argument("--frames", type=int, default=125, help="frames per request (10 s of audio); codec EOS is ignored")
     ap.add_argument("--prompt-len", type=int, default=48)
     ap.add_argument("--sample", action="store_true", help="the reference's sampling (T=1.0/0.9, top-k 50) instead of greedy")
+    ap.add_argument("--embeds", action="store_true", help="skip the text front-end: hand synthetic embeddings to generate()")
     args = ap.parse_args()
 
     from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
@@ -31,13 +36,21 @@ def main():
     iface.ignore_eos = True
     H = iface.model_config.talker_config.hidden_size
     prompt, trailing, pad = request(H, args.prompt_len, 20, seed=1000)
+    if iface.processor is None:
+        iface.processor = CharProcessor(iface.model_config.talker_config.text_vocab_size)
 
-    list(iface.generate(prompt, trailing, pad, max_frames=8))                 # warm-up: graphs captured here
+    def start(n):
+        if args.embeds:
+            return iface.generate(prompt, trailing, pad, max_frames=n)
+        iface.max_frames = n
+        return iface.generate_voice_design(text=TEXT, instruct=INSTRUCT, language="English")
+
+    list(start(8))                                                            # warm-up: graphs captured here
     times, first = [], []
     n_frames = 0
     for _ in range(args.runs):
         t0 = time.perf_counter()
-        gen = iface.generate(prompt, trailing, pad, max_frames=args.frames)
+        gen = start(args.frames)
         frames = [next(gen)]
         first.append(time.perf_counter() - t0)
         frames += list(gen)
@@ -50,7 +63,8 @@ def main():
                       "audio_seconds": audio_s, "avg_generation_s": avg, "rtf": avg / audio_s,
                       "first_frame_ms_p50": statistics.median(first) * 1e3,
                       "codec_tokens_per_s": 16 * n_frames / avg, "sampling": "reference" if args.sample else "greedy",
-                      "data": "synthetic embeddings, random-init weights; codec decode not included"}))
+                      "entry": "generate(embeds)" if args.embeds else "generate_voice_design(text, instruct)",
+                      "data": "random-init weights, character-level stand-in tokenizer; codec decode not included"}))
     iface.shutdown()
 
 

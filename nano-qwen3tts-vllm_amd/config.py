@@ -56,7 +56,13 @@ _PRED_DEFAULTS = dict(vocab_size=2048, hidden_size=1024, intermediate_size=3072,
 _TALKER_DEFAULTS = dict(vocab_size=3072, hidden_size=1024, intermediate_size=2048, num_hidden_layers=20,
                         num_attention_heads=16, num_key_value_heads=2, head_dim=None, rms_norm_eps=1e-6,
                         rope_theta=10000, rope_scaling=None, attention_bias=False, num_code_groups=16,
-                        text_vocab_size=151936, text_hidden_size=2048, max_position_embeddings=32768)
+                        text_vocab_size=151936, text_hidden_size=2048, max_position_embeddings=32768, hidden_act="silu",
+                        # special codec ids and the speaker / language tables of the prompt layout (P/config.py:473-509)
+                        codec_eos_token_id=4198, codec_think_id=4202, codec_nothink_id=4203, codec_think_bos_id=4204,
+                        codec_think_eos_id=4205, codec_pad_id=4196, codec_bos_id=4197, spk_id=None, spk_is_dialect=None,
+                        codec_language_id=None)
+_TOP_DEFAULTS = dict(tts_model_size=None, tts_model_type=None, im_start_token_id=151644, im_end_token_id=151645,
+                     tts_pad_token_id=151671, tts_bos_token_id=151672, tts_eos_token_id=151673)     # P/config.py:575-609
 
 
 class Qwen3TTSConfig:
@@ -67,7 +73,12 @@ class Qwen3TTSConfig:
         self.talker_config._d["code_predictor_config"] = _NS(pc, _PRED_DEFAULTS)
         if self.talker_config.head_dim is None:
             self.talker_config._d["head_dim"] = self.talker_config.hidden_size // self.talker_config.num_attention_heads
+        for k in ("spk_id", "spk_is_dialect", "codec_language_id"):
+            if self.talker_config._d[k] is None:
+                self.talker_config._d[k] = {}
         self.extra = kw
+        for k, v in _TOP_DEFAULTS.items():
+            setattr(self, k, kw.get(k, v))
 
     @staticmethod
     def from_model_dir(path: str) -> "Qwen3TTSConfig":

@@ -1,13 +1,15 @@
 """Qwen3TTSInterface — the API object applications hold
 (reference: P/interface.py:338-1366).
 
-What this build implements of it is the decode path: the asynchronous per-frame loop that glues
-talker and predictor through the worker clients (`generate_async`, reference :1184-1308) and the
-synchronous in-process loop (`generate`, the reference's disabled `_generate_caller_driven`,
-:1310-1366), here driven by the device-resident FrameEngine.  Turning text, speaker and
-reference audio into input embeddings (tokenizer, prompt layout, speaker encoder, codec) lives in
-third-party packages and model files that are not part of the decode path; the corresponding
-methods keep their names and signatures and raise NotImplementedError.
+What this build implements of it: the decode path — the asynchronous per-frame loop (`generate_async`,
+reference :1184-1308) and the synchronous in-process loop (`generate`, the reference's disabled
+`_generate_caller_driven`, :1310-1366), both on the device-resident FrameEngine by default — and the prompt
+front-end that turns text, instruction, speaker, language and a ready voice-clone prompt into talker input
+embeddings (`generate_voice_design`, `generate_custom_voice(_async)`, `generate_voice_clone(_async)`,
+reference :723-1171, on utils/generation.py + utils/prompt.py).  The text entry points need the tokenizer
+files in the model directory (or a `processor` assigned by the caller) and the text tables in the
+checkpoint.  Reference audio -> voice-clone prompt (speaker encoder, speech codec) and codes -> PCM live in
+third-party packages; `create_voice_clone_prompt` keeps its signature and raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -61,19 +63,15 @@ def _compute_memory_split(model_path: str, gpu_memory_utilization: float, kvcach
             "process_gpu_memory_fraction": gpu_memory_utilization}
 
 
-def _load_codec_embeddings(model_path: str, device):
-    """fp32 copies of the codec embedding tables the frame glue needs (the reference keeps fp32 copies of
-    the bf16 weights in the API process, P/utils/embedding_loader.py:40-50,72)."""
-    from safetensors import safe_open
-    tables = {}
-    with safe_open(os.path.join(model_path, "model.safetensors"), framework="pt", device="cpu") as f:
-        for k in f.keys():
-            if k == "talker.model.codec_embedding.weight" or k.startswith("talker.code_predictor.model.codec_embedding."):
-                tables[k] = f.get_tensor(k).float().to(device)
-    inp = tables["talker.model.codec_embedding.weight"]
-    n = sum(1 for k in tables if k.startswith("talker.code_predictor."))
-    preds = [tables[f"talker.code_predictor.model.codec_embedding.{i}.weight"] for i in range(n)]
-    return inp, preds
+def _get_processor(model_path: str):
+    """The tokenizer in the model directory behind the processor call signature (P/interface.py:217-222);
+    None when the directory holds no tokenizer files (decode-only synthetic directories)."""
+    try:
+        from .processor import Qwen3TTSProcessor
+        return Qwen3TTSProcessor.from_pretrained(model_path)
+    except Exception as e:
+        logger.info(f"[interface] no tokenizer in {model_path}: {type(e).__name__}")
+        return None
 
 
 class Qwen3TTSInterface:
@@ -85,11 +83,12 @@ class Qwen3TTSInterface:
         self.tensor_parallel_size = self._tensor_parallel_size = tensor_parallel_size
         self._gpu_memory_utilization = gpu_memory_utilization
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        self.model_config = Qwen3TTSConfig.from_model_dir(model_path)
-        self.input_embedding_weight, self.predictor_embedding_weights = _load_codec_embeddings(model_path, self.device)
-        self.input_embedding = lambda ids: self.input_embedding_weight[ids]
-        self.predictor_input_embeddings = [(lambda ids, w=w: w[ids]) for w in self.predictor_embedding_weights]
-        self.text_embedding = self.text_projection = self.processor = None      # prompt front-end: not in this build
+        from .utils.embedding_loader import load_embeddings_only
+        (self.model_config, self.text_embedding, self.input_embedding, self.text_projection,
+         self.predictor_input_embeddings) = load_embeddings_only(model_path, device=str(self.device))
+        self.input_embedding_weight = self.input_embedding.weight
+        self.predictor_embedding_weights = [t.weight for t in self.predictor_input_embeddings]
+        self.processor = _get_processor(model_path)
         self.speech_tokenizer = None
         self.speaker_encoder = None
         self.talker_llm = self.predictor_llm = None
@@ -364,32 +363,104 @@ class Qwen3TTSInterface:
         finally:
             fe.remove_stream(sid)
 
-    # ---------------------------------------------------------------- text / audio front-end (not in this build)
-    def _front_end(self, what: str):
-        raise NotImplementedError(
-            f"{what}: building input embeddings from text / speakers / reference audio needs the tokenizer, the "
-            "text embedding tables and the speech codec, which are outside this build's decode path; call "
-            "generate()/generate_async() with inputs_embeds, trailing_text_hiddens and tts_pad_embed instead")
+    # ---------------------------------------------------------------- text front-end
+    def _need_front_end(self, what: str):
+        if self.processor is None:
+            raise RuntimeError(f"{what}: no tokenizer found in {self.model_path}; put the tokenizer files there or "
+                               "assign `interface.processor` (callable as processor(text=..., return_tensors='pt', padding=True))")
+        if self.text_embedding is None or self.text_projection is None:
+            raise RuntimeError(f"{what}: the checkpoint in {self.model_path} has no text embedding / projection tables")
+
+    def _prep_custom_voice(self, text, language, speaker, instruct=None, non_streaming_mode=True):
+        from .utils.generation import prepare_inputs
+        from .utils.prompt import prepare_custom_voice_prompt
+        input_ids, instruct_ids, speakers, languages = prepare_custom_voice_prompt(
+            text=[text], speaker=[speaker], language=[language], instruct=None if instruct is None else [instruct],
+            processor=self.processor, device=self.device)
+        return prepare_inputs(config=self.model_config, input_ids=input_ids, instruct_ids=instruct_ids, languages=languages,
+                              speakers=None if speaker == "" else speakers, non_streaming_mode=non_streaming_mode,
+                              text_embedding=self.text_embedding, input_embedding=self.input_embedding,
+                              text_projection=self.text_projection, device=self.device)
+
+    def _prep_voice_clone(self, text, language, ref_audio, ref_text, x_vector_only_mode, voice_clone_prompt, non_streaming_mode):
+        """Reference :761-842.  The prompt dict holds ref_code [T,16] or None, ref_spk_embedding [D],
+        x_vector_only_mode, icl_mode and optionally ref_text."""
+        from .utils.generation import generate_icl_prompt, generate_speaker_prompt, prepare_inputs
+        from .utils.prompt import _build_assistant_text, _build_ref_text, _tokenize_texts
+        if voice_clone_prompt is None:
+            if ref_audio is None:
+                raise ValueError("Either `voice_clone_prompt` or `ref_audio` must be provided.")
+            voice_clone_prompt = self.create_voice_clone_prompt(ref_audio=ref_audio, ref_text=ref_text,
+                                                                x_vector_only_mode=x_vector_only_mode)
+            ref_text_for_ids = ref_text
+        elif voice_clone_prompt.get("icl_mode", False):
+            ref_text_for_ids = ref_text if ref_text is not None else voice_clone_prompt.get("ref_text")
+            if ref_text_for_ids is None:
+                raise ValueError("ICL mode is enabled in voice_clone_prompt but ref_text is not available. Please provide "
+                                 "ref_text when creating voice_clone_prompt or when calling generate_voice_clone.")
+        else:
+            ref_text_for_ids = None
+        input_ids = _tokenize_texts([_build_assistant_text(text)], self.processor, self.device)
+        ref_ids = None
+        if ref_text_for_ids:
+            ref_ids = [_tokenize_texts([_build_ref_text(ref_text_for_ids)], self.processor, self.device)[0]]
+        lists = {k: [voice_clone_prompt[k]] for k in ("ref_code", "ref_spk_embedding", "x_vector_only_mode", "icl_mode")}
+
+        def icl_fn(**kw):
+            return generate_icl_prompt(config=self.model_config, text_embedding=self.text_embedding,
+                                       input_embedding=self.input_embedding, text_projection=self.text_projection,
+                                       code_predictor_embeddings=self.predictor_input_embeddings, device=self.device, **kw)
+        return prepare_inputs(config=self.model_config, input_ids=input_ids, ref_ids=ref_ids, voice_clone_prompt=lists,
+                              languages=[language or "Auto"], non_streaming_mode=non_streaming_mode,
+                              text_embedding=self.text_embedding, input_embedding=self.input_embedding,
+                              text_projection=self.text_projection, device=self.device,
+                              generate_speaker_prompt_fn=lambda p: generate_speaker_prompt(p, self.device),
+                              generate_icl_prompt_fn=icl_fn)
+
+    def _run_sync(self, prepared):
+        embeds, trailing, pad, _mask = prepared
+        return self._generate_caller_driven(embeds, trailing, pad, str(uuid.uuid4()),
+                                            SamplingParams(temperature=1.0, max_tokens=1, do_sample=self.do_sample),
+                                            SamplingParams(temperature=0.9, max_tokens=17, do_sample=self.do_sample))
 
     def generate_custom_voice(self, text: str, language: str = "English", speaker: str = "Vivian"):
-        self._front_end("generate_custom_voice")
+        """Generator of 16-id frames for a built-in speaker (reference :1121-1143; its sync form is disabled there
+        in favour of the async one — both work here)."""
+        self._need_front_end("generate_custom_voice")
+        return self._run_sync(self._prep_custom_voice(text, language, speaker))
 
     async def generate_custom_voice_async(self, text: str, language: str = "English", speaker: str = "Vivian"):
-        self._front_end("generate_custom_voice_async")
-        yield []          # pragma: no cover
+        if not self._zmq_tasks_started:
+            raise RuntimeError("generate_custom_voice_async requires start_zmq_tasks() to be called first")
+        self._need_front_end("generate_custom_voice_async")
+        embeds, trailing, pad, mask = self._prep_custom_voice(text, language, speaker)
+        async for frame in self.generate_async(embeds, trailing, pad, mask):
+            yield frame
 
     def generate_voice_design(self, text: str, instruct: str, language: str | None = None, non_streaming_mode: bool = True):
-        self._front_end("generate_voice_design")
+        """Voice described by a natural-language instruction, no speaker embedding (reference :1013-1079)."""
+        self._need_front_end("generate_voice_design")
+        return self._run_sync(self._prep_custom_voice(text, language or "Auto", "", instruct, non_streaming_mode))
 
-    def generate_voice_clone(self, text: str, language: str = "English", ref_audio=None, ref_text=None,
+    def generate_voice_clone(self, text: str, language: str | None = None, ref_audio=None, ref_text=None,
                              x_vector_only_mode: bool = False, voice_clone_prompt=None, non_streaming_mode: bool = True):
-        self._front_end("generate_voice_clone")
+        self._need_front_end("generate_voice_clone")
+        return self._run_sync(self._prep_voice_clone(text, language, ref_audio, ref_text, x_vector_only_mode,
+                                                     voice_clone_prompt, non_streaming_mode))
 
-    async def generate_voice_clone_async(self, text: str, language: str = "English", ref_audio=None, ref_text=None,
+    async def generate_voice_clone_async(self, text: str, language: str | None = None, ref_audio=None, ref_text=None,
                                          x_vector_only_mode: bool = False, voice_clone_prompt=None,
                                          non_streaming_mode: bool = True):
-        self._front_end("generate_voice_clone_async")
-        yield []          # pragma: no cover
+        if not self._zmq_tasks_started:
+            raise RuntimeError("generate_voice_clone_async requires start_zmq_tasks() to be called first")
+        self._need_front_end("generate_voice_clone_async")
+        embeds, trailing, pad, mask = self._prep_voice_clone(text, language, ref_audio, ref_text, x_vector_only_mode,
+                                                             voice_clone_prompt, non_streaming_mode)
+        async for frame in self.generate_async(embeds, trailing, pad, mask):
+            yield frame
 
     def create_voice_clone_prompt(self, ref_audio, ref_text=None, x_vector_only_mode: bool = False):
-        self._front_end("create_voice_clone_prompt")
+        raise NotImplementedError(
+            "create_voice_clone_prompt: turning reference audio into codec frames and a speaker vector needs the speech "
+            "codec and the speaker encoder, which ship in third-party packages outside this build; pass a ready "
+            "`voice_clone_prompt` dict (ref_code, ref_spk_embedding, x_vector_only_mode, icl_mode, ref_text) instead")

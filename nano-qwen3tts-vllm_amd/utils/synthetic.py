@@ -60,7 +60,15 @@ def make_config(size: str = "1.7B") -> dict:
             num_code_groups=16,
         ),
     )
-    return dict(talker_config=talker, tts_model_size=size, tts_model_type="voice_design")
+    # special ids of the prompt layout, placed at the top of each vocabulary
+    V, TV = talker["vocab_size"], talker["text_vocab_size"]
+    talker.update(codec_pad_id=V - 12, codec_bos_id=V - 11, codec_eos_token_id=V - 10, codec_think_id=V - 9,
+                  codec_nothink_id=V - 8, codec_think_bos_id=V - 7, codec_think_eos_id=V - 6,
+                  codec_language_id={"english": V - 20, "chinese": V - 19, "sichuan_dialect": V - 18},
+                  spk_id={"vivian": V - 30, "eric": V - 29}, spk_is_dialect={"eric": "sichuan_dialect"}, hidden_act="silu")
+    return dict(talker_config=talker, tts_model_size=size, tts_model_type="voice_design",
+                tts_pad_token_id=TV - 4, tts_bos_token_id=TV - 3, tts_eos_token_id=TV - 2,
+                im_start_token_id=TV - 6, im_end_token_id=TV - 5)
 
 
 def _decoder_keys(prefix, n_layers, hidden, heads, kv_heads, head_dim, inter):

@@ -345,6 +345,7 @@ def main():
     gen_models(ref, syn, "tiny-id", 12, "tiny_id")
     gen_sched(ref)
     gen_protocol(ref)
+    gen_frontend(ref, syn)
 
 
 def gen_protocol(ref):
@@ -368,8 +369,128 @@ def gen_protocol(ref):
     print("protocol.npz", {k: len(v) for k, v in msgs.items()})
 
 
+class CharProcessor:
+    """Deterministic stand-in tokenizer for fixtures (no tokenizer files exist offline): the three chat markers
+    are single ids, every other character is its code point folded into the vocabulary."""
+
+    MARKS = {"<|im_start|>": 1, "<|im_end|>": 2}
+
+    def __init__(self, vocab):
+        self.vocab = vocab
+
+    def __call__(self, text=None, return_tensors="pt", padding=True):
+        text = text[0] if isinstance(text, list) else text
+        ids, i = [], 0
+        while i < len(text):
+            for m, v in self.MARKS.items():
+                if text.startswith(m, i):
+                    ids.append(v)
+                    i += len(m)
+                    break
+            else:
+                ids.append(3 + ord(text[i]) % (self.vocab - 10))
+                i += 1
+        return {"input_ids": torch.tensor([ids], dtype=torch.long)}
+
+
+def gen_frontend(ref, syn):
+    """Prompt construction fixtures: the reference's prepare_inputs / generate_icl_prompt /
+    prepare_custom_voice_prompt (P/utils/generation.py, P/utils/prompt.py) on a tiny synthetic checkpoint's
+    fp32 tables and a character tokenizer, for every request kind the API object builds."""
+    gen = importlib.import_module("nano_qwen3tts_vllm.utils.generation")
+    prompt = importlib.import_module("nano_qwen3tts_vllm.utils.prompt")
+    cfgmod = importlib.import_module("nano_qwen3tts_vllm.config")
+    talker_mod = importlib.import_module("nano_qwen3tts_vllm.models.qwen3_tts_talker")
+    cfg = syn.make_config("tiny")
+    sd = syn.make_state_dict(cfg, seed=21, with_text=True, embed_std=0.05, std=0.2)
+    config = cfgmod.Qwen3TTSConfig(**cfg)
+    tc = config.talker_config
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float32)
+    text_embedding = torch.nn.Embedding(tc.text_vocab_size, tc.text_hidden_size)
+    input_embedding = torch.nn.Embedding(tc.vocab_size, tc.hidden_size)
+    proj = talker_mod.Qwen3TTSTalkerResizeMLP(tc.text_hidden_size, tc.text_hidden_size, tc.hidden_size, tc.hidden_act, bias=True)
+    with torch.no_grad():
+        text_embedding.weight.copy_(sd["talker.model.text_embedding.weight"].float())
+        input_embedding.weight.copy_(sd["talker.model.codec_embedding.weight"].float())
+        proj.linear_fc1.weight.copy_(sd["talker.text_projection.linear_fc1.weight"].float())
+        proj.linear_fc1.bias.copy_(sd["talker.text_projection.linear_fc1.bias"].float())
+        proj.linear_fc2.weight.copy_(sd["talker.text_projection.linear_fc2.weight"].float())
+        proj.linear_fc2.bias.copy_(sd["talker.text_projection.linear_fc2.bias"].float())
+    preds = []
+    for i in range(15):
+        e = torch.nn.Embedding(tc.code_predictor_config.vocab_size, tc.hidden_size)
+        with torch.no_grad():
+            e.weight.copy_(sd[f"talker.code_predictor.model.codec_embedding.{i}.weight"].float())
+        preds.append(e)
+    processor = CharProcessor(tc.text_vocab_size)
+    dev = torch.device("cpu")
+    g = torch.Generator().manual_seed(77)
+    out, meta = {}, {"seed": 21, "cases": []}
+
+    def icl_fn(**kw):
+        return gen.generate_icl_prompt(config=config, text_embedding=text_embedding, input_embedding=input_embedding,
+                                       text_projection=proj, code_predictor_embeddings=preds, device=dev, **kw)
+
+    def record(name, res, **info):
+        emb, tail, pad, mask = res
+        out[name + "_embeds"], out[name + "_tail"], out[name + "_pad"], out[name + "_mask"] = f32(emb), f32(tail), f32(pad), mask.numpy()
+        meta["cases"].append(dict(name=name, **info))
+
+    common = dict(text_embedding=text_embedding, input_embedding=input_embedding, text_projection=proj, device=dev)
+    with torch.no_grad():
+        # voice design: instruction, no speaker; streaming and non-streaming; language auto / named
+        for name, lang, ns in (("design_ns", "Auto", True), ("design_stream", "English", False)):
+            ids, ins, spk, langs = prompt.prepare_custom_voice_prompt(text=["Hello there, world."], speaker=[""], language=[lang],
+                                                                      instruct=["A calm low voice"], processor=processor, device=dev)
+            out[name + "_ids"], out[name + "_ins"] = ids[0].numpy(), ins[0].numpy()
+            record(name, gen.prepare_inputs(config, ids, instruct_ids=ins, languages=langs, speakers=None,
+                                            non_streaming_mode=ns, **common),
+                   kind="design", language=lang, non_streaming=ns, text="Hello there, world.", instruct="A calm low voice")
+        # custom voice: named speakers (one a dialect speaker), a batch of two with different lengths
+        texts = ["Good morning.", "A much longer sentence to be spoken by the second speaker."]
+        ids, ins, spk, langs = prompt.prepare_custom_voice_prompt(text=texts, speaker=["Vivian", "Eric"], language=["English", "Chinese"],
+                                                                  processor=processor, device=dev)
+        out["custom_ids0"], out["custom_ids1"] = ids[0].numpy(), ids[1].numpy()
+        record("custom", gen.prepare_inputs(config, ids, instruct_ids=ins, speakers=spk, languages=langs,
+                                            non_streaming_mode=True, **common),
+               kind="custom", texts=texts, speakers=["Vivian", "Eric"], languages=["English", "Chinese"], non_streaming=True)
+        record("custom_stream", gen.prepare_inputs(config, ids, instruct_ids=ins, speakers=spk, languages=langs,
+                                                   non_streaming_mode=False, **common),
+               kind="custom", texts=texts, speakers=["Vivian", "Eric"], languages=["English", "Chinese"], non_streaming=False)
+        # voice clone: speaker vector only, and in-context with reference codes (text longer / shorter than the codes)
+        spk_vec = torch.randn(tc.hidden_size, generator=g) * 0.1
+        out["clone_spk"] = f32(spk_vec)
+        ids = prompt._tokenize_texts([prompt._build_assistant_text("Clone this voice please.")], processor, dev)
+        out["clone_ids"] = ids[0].numpy()
+        vc = {"ref_code": [None], "ref_spk_embedding": [spk_vec], "x_vector_only_mode": [True], "icl_mode": [False]}
+        record("clone_xvec", gen.prepare_inputs(config, ids, voice_clone_prompt=vc, languages=["Auto"], non_streaming_mode=True,
+                                                generate_speaker_prompt_fn=lambda p: gen.generate_speaker_prompt(p, dev),
+                                                generate_icl_prompt_fn=icl_fn, **common),
+               kind="clone_xvec", text="Clone this voice please.")
+        ref_ids = prompt._tokenize_texts(["<|im_start|>assistant\nReference words.<|im_end|>\n"], processor, dev)
+        out["clone_ref_ids"] = ref_ids[0].numpy()
+        for name, frames, ns in (("clone_icl_short", 6, False), ("clone_icl_long", 60, False), ("clone_icl_ns", 6, True)):
+            code = torch.randint(0, tc.code_predictor_config.vocab_size, (frames, 16), generator=g)
+            out[name + "_code"] = code.numpy()
+            vc = {"ref_code": [code], "ref_spk_embedding": [spk_vec], "x_vector_only_mode": [False], "icl_mode": [True]}
+            record(name, gen.prepare_inputs(config, ids, ref_ids=ref_ids, voice_clone_prompt=vc, languages=["English"],
+                                            non_streaming_mode=ns,
+                                            generate_speaker_prompt_fn=lambda p: gen.generate_speaker_prompt(p, dev),
+                                            generate_icl_prompt_fn=icl_fn, **common),
+                   kind="clone_icl", text="Clone this voice please.", ref_text="Reference words.", non_streaming=ns)
+    torch.set_default_dtype(old)
+    np.savez_compressed(os.path.join(OUT, "frontend.npz"), **out)
+    with open(os.path.join(OUT, "frontend.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("frontend.npz", {c["name"]: out[c["name"] + "_embeds"].shape for c in meta["cases"]})
+
+
 if __name__ == "__main__":
-    if "--protocol-only" in sys.argv:
+    if "--frontend-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        gen_frontend(ref_harness.load_reference(), _load_synthetic())
+    elif "--protocol-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         gen_protocol(ref_harness.load_reference())
     else:

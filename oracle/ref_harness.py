@@ -31,6 +31,9 @@ def _flash_attn_module():
     import torch
 
     mod = types.ModuleType("flash_attn")
+    # libraries that probe for optional packages with importlib.util.find_spec need a spec on the stand-in
+    import importlib.machinery
+    mod.__spec__ = importlib.machinery.ModuleSpec("flash_attn", None)
 
     def _attend(q, k, v, scale, causal_offset):
         # q [Lq,Hq,D], k/v [Lk,Hkv,D]; fp32 textbook attention.

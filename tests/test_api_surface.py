@@ -208,7 +208,9 @@ def test_interface_rejects_missing_path_and_front_end(model_dir):
     with pytest.raises(ValueError):
         Qwen3TTSInterface.from_pretrained("/nonexistent/model/dir")
     iface = Qwen3TTSInterface(model_dir)
+    with pytest.raises(RuntimeError, match="no tokenizer"):
+        iface.generate_voice_design("hi", "a calm voice")          # the synthetic directory has no tokenizer files
     with pytest.raises(NotImplementedError):
-        iface.generate_voice_design("hi", "a calm voice")
+        iface.create_voice_clone_prompt(ref_audio="ref.wav", ref_text="hello")
     with pytest.raises(AssertionError):
         Qwen3TTSInterface(model_dir, tensor_parallel_size=2)

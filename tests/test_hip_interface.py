@@ -130,3 +130,31 @@ def test_sync_generate_matches_fixture(model):
         assert len(got) == 6
         check(got, want[i], margins[i])
     iface.shutdown()
+
+
+def test_voice_design_text_entry_point(tmp_path):
+    """Text in, frames out: generate_voice_design / generate_custom_voice_async build the prompt with the
+    front-end and run it on the engine; same frames as handing the prepared embeddings to generate()."""
+    from test_frontend import CharProcessor
+    from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
+    from nano_qwen3tts_vllm.utils import synthetic
+    d = str(tmp_path)
+    synthetic.write_model_dir(d, "tiny", seed=21, with_text=True, embed_std=0.05, std=0.2)
+    iface = Qwen3TTSInterface.from_pretrained(d, gpu_memory_utilization=0.05)
+    iface.processor = CharProcessor(iface.model_config.talker_config.text_vocab_size)
+    iface.do_sample = False
+    iface.max_frames = 5
+    got = list(iface.generate_voice_design("Hello there, world.", "A calm low voice", language="English"))
+    emb, tail, pad, _ = iface._prep_custom_voice("Hello there, world.", "English", "", "A calm low voice", True)
+    want = list(iface.generate(emb, tail, pad, None, max_frames=5))
+    assert len(got) == 5 and all(len(f) == 16 for f in got) and got == want
+
+    async def run():
+        await iface.start_zmq_tasks()
+        a = [f async for f in iface.generate_custom_voice_async("Good morning.", language="English", speaker="Vivian")]
+        await iface.stop_zmq_tasks()
+        return a
+    a = asyncio.run(run())
+    b = list(iface.generate_custom_voice("Good morning.", language="English", speaker="Vivian"))
+    assert len(a) == 5 and a == b
+    iface.shutdown()
