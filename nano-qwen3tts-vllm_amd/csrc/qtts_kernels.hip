@@ -186,11 +186,22 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     const int NW = blockDim.x >> 6;
     const int g = lane >> 4, r = lane & 15;
     const int KS = p.K >> 5;
-    const int m = blockIdx.y * 16 + r;
+    // Several row tiles (prefill): the launch is one-dimensional and the workgroups that share a weight tile are
+    // placed on the same XCD, next to each other in dispatch order (workgroup i runs on XCD i % 8), so the tile
+    // comes from HBM once and the other row tiles find it in that XCD's L2.
+    int bx = blockIdx.x, by = 0;
+    const int mtiles = p.dbg >> 8;
+    if (mtiles > 1) {
+        const int per = 8 * mtiles, grp = blockIdx.x / per, rem = blockIdx.x % per;
+        bx = grp * 8 + (rem & 7);
+        by = rem >> 3;
+        if (bx * p.tiles_per_wg >= (p.N >> 4)) return;
+    }
+    const int m = by * 16 + r;
     const bool mvalid = m < p.M;
     const int ks0 = wave * KSW;
     const int ntiles = p.N >> 4;
-    const int t_begin = blockIdx.x * p.tiles_per_wg;
+    const int t_begin = bx * p.tiles_per_wg;
     const int t_end = min(t_begin + p.tiles_per_wg, ntiles);
 
     // ---- activation prologue
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
                 o4[j] = pack2(rbf(v0 * rstd) * w0, rbf(v1 * rstd) * w1);
             }
             xb[i].u = make_uint4(o4[0], o4[1], o4[2], o4[3]);
-            if (p.xnorm_out && blockIdx.x == 0 && mvalid)
+            if (p.xnorm_out && bx == 0 && mvalid)
                 *reinterpret_cast<uint4 *>(p.xnorm_out + (size_t)m * p.ldxn + k) = xb[i].u;
         }
     }
@@ -391,7 +402,12 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     if (silu_pairs) QCHECK(db, "linear: the SwiGLU epilogue needs K <= 3072 (K=%d)", a.K);
     a.tiles_per_wg = tpw;
     a.dbg = g_dbg_linear;
-    dim3 grid((ntiles + tpw - 1) / tpw, (a.M + 15) / 16);
+    const int gx = (ntiles + tpw - 1) / tpw, gy = (a.M + 15) / 16;
+    dim3 grid(gx, 1);
+    if (gy > 1) {
+        a.dbg |= gy << 8;                                  // row-tile count rides above the experiment bits
+        grid = dim3(((gx + 7) / 8) * 8 * gy, 1);
+    }
 #define QL2(KSW_, DB_) case KSW_: \
         if (silu_pairs && DB_) { if (pro == 1) launch_linear2_inst<KSW_, 1, DB_, DB_ ? 1 : 0>(grid, NW, s, a); \
                                  else launch_linear2_inst<KSW_, 0, DB_, DB_ ? 1 : 0>(grid, NW, s, a); } \
