@@ -229,6 +229,25 @@ class FrameEngine:
             g = self.graphs[key] = hip.Graph.capture(lambda: self._frame_body(bs, max_ctx))
         g.launch()
 
+    def capture_all(self, max_context: int | None = None) -> int:
+        """Captures the frame graph of every (batch bucket, context bucket) this engine can meet, so that no
+        capture happens while streams are being served (the reference captures its decode graphs at start-up
+        too, P/engine/model_runner/talker_mode_runner.py:157-192).  Returns the number of graphs held."""
+        if self.enforce_eager:
+            return 0
+        top = min(max_context or self.tr.config.max_model_len, self.tr.config.max_model_len)
+        with self.tr.on_stream():
+            for bs in (b for b in self.tr.graph_bs if b <= self._bucket_for(self.max_streams)):
+                self.pr.prepare_resident(bs)
+                for ctx in range(128, top + 1, 128):
+                    if (bs, ctx) not in self.graphs:
+                        self.graphs[(bs, ctx)] = hip.Graph.capture(lambda: self._frame_body(bs, ctx))
+            self.tr.stream.synchronize()
+        return len(self.graphs)
+
+    def _bucket_for(self, n: int) -> int:
+        return next(b for b in self.tr.graph_bs if b >= max(n, 1))
+
     def run_frames(self, n: int) -> torch.Tensor:
         """Generate n frames for every active stream back to back (no EOS handling: the caller asked
         for exactly n).  Returns ids [n, bucket, 16] on the host; one synchronisation at the end."""

@@ -142,7 +142,9 @@ class Qwen3TTSInterface:
             return
         self._zmq_tasks_started = True
         if self._async_engine == "fused":
-            self._engine(self.max_streams)
+            fe = self._engine(self.max_streams)
+            if os.environ.get("QTTS_CAPTURE_AT_START", "1") != "0":
+                fe.capture_all()                     # no graph capture while streams are being served
             self._fused_wake = asyncio.Event()
             self._fused_task = asyncio.create_task(self._run_fused_loop())
             return

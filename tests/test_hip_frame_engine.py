@@ -90,3 +90,29 @@ def test_frame_engine_step_eos_and_late_join(tmp_path):
     assert got_b == solo_b[:len(got_b)] and len(got_b) == 5
     assert a not in fe.streams
     fe.exit()
+
+
+def test_capture_all_then_no_capture_while_serving(tmp_path):
+    """Every (batch bucket, context bucket) graph is captured up front; serving a stream across a context
+    bucket boundary then reuses them (no new graph) and yields the ids of an engine that captures lazily."""
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    cfg, sd, tw, pw = golden_weights("tiny", 11)
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(9)
+    H = cfg["talker_config"]["hidden_size"]
+    prompt, text = torch.randn(120, H, generator=gen) * 0.5, torch.randn(4, H, generator=gen) * 0.3
+    kw = dict(max_streams=2, max_text_frames=16, talker_weights=tw, predictor_weights=pw, num_kvcache_blocks=8,
+              max_num_batched_tokens=1024, codec_eos=None)
+    outs = []
+    for eager_capture in (True, False):
+        fe = FrameEngine(str(tmp_path), **kw)
+        if eager_capture:
+            n = fe.capture_all()
+            assert n == 2 * 8                 # batch buckets {1, 2} x context buckets {128, ..., 1024}
+        fe.add_stream(prompt, text, max_frames=12, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+        frames = [fe.step()["stream-0"] for _ in range(12)]          # context 121 -> 133: crosses the 128 boundary
+        if eager_capture:
+            assert len(fe.graphs) == n
+        outs.append(frames)
+        fe.exit()
+    assert outs[0] == outs[1]

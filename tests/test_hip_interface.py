@@ -83,6 +83,7 @@ def test_fused_async_continuous_batching(model, monkeypatch):
 
     async def run():
         await iface.start_zmq_tasks()
+        total_blocks = len(iface._frame_engine.talker.scheduler.block_manager.free_block_ids)
 
         async def one(i, delay):
             await asyncio.sleep(delay)
@@ -96,27 +97,18 @@ def test_fused_async_continuous_batching(model, monkeypatch):
         res = await asyncio.gather(one(0, 0), one(1, 0), one(0, 0.002), one(1, 0.01), early())
         await asyncio.sleep(0.01)
         fe = iface._frame_engine
-        state = (len(fe.streams), len(fe.talker.scheduler.block_manager.free_block_ids), dict(iface._request_queues))
+        state = (len(fe.streams), len(fe.talker.scheduler.block_manager.free_block_ids) - total_blocks, dict(iface._request_queues))
         await iface.stop_zmq_tasks()
         return res, state
 
-    res, (n_streams, free_blocks, queues) = asyncio.run(run())
+    res, (n_streams, missing_blocks, queues) = asyncio.run(run())
     for got, i in zip(res[:4], (0, 1, 0, 1)):
         assert len(got) == 6
         check(got, want[i], margins[i])
     assert list(res[4]) == list(res[0][0])
     assert n_streams == 0 and not queues
     iface.shutdown()
-    assert free_blocks == iface_free_blocks_total(d)
-
-
-def iface_free_blocks_total(d):
-    """Blocks a fresh frame engine of the same configuration starts with."""
-    from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
-    iface = Qwen3TTSInterface.from_pretrained(d, gpu_memory_utilization=0.05)
-    n = len(iface._engine(2).talker.scheduler.block_manager.free_block_ids)
-    iface.shutdown()
-    return n
+    assert missing_blocks == 0                # every KV block went back to the free list
 
 
 def test_sync_generate_matches_fixture(model):
