@@ -131,6 +131,9 @@ static int g_tune_t = 0;
 static int g_dbg_linear = 0;
 extern "C" void qtts_tune_linear(int ksw, int t) { g_tune_ksw = ksw; g_tune_t = t; }
 extern "C" void qtts_debug_linear(int flags) { g_dbg_linear = flags; }
+static long long *g_trace = nullptr;       // tuning experiments only: timestamp buffer of traced GEMM launches
+static int g_trace_launch = 0;
+extern "C" void qtts_debug_linear_trace(long long *buf) { g_trace = buf; g_trace_launch = 0; }
 
 // ------------------------------------------------------------------ linear (skinny GEMM on MFMA)
 // One kernel shape for every projection.  Workgroup = NW <= 8 waves, wave w owns
@@ -150,7 +153,7 @@ struct LinArgs {
     bf16_t *xnorm_out; int ldxn;
     bf16_t *out; int ldo;
     int M, N, K, tiles_per_wg;
-    int dbg;      // tuning experiments only (0 in production): bit0 every tile reads weight tile 0, bit1 skip x loads
+    int dbg;      // bit0: tuning experiment (every tile reads weight tile 0); bits 8+: row-tile count of a prefill launch
 };
 
 __device__ __forceinline__ void unpack2(uint32_t w, float &a, float &b) {
@@ -170,12 +173,16 @@ struct LinTail {
     const bf16_t *bias, *res; int ldr;
     bf16_t *xnorm_out; int ldxn;
     bf16_t *out; int ldo;
+    long long *trace;     // tuning experiments only (null in production): 4 timestamps per workgroup
 };
+#define QTTS_TRACE(slot) do { if (tl.trace && threadIdx.x == 0) tl.trace[(size_t)blockIdx.x * 4 + (slot)] = wall_clock64(); } while (0)
 
 template <int KSW, int PRO, bool DB, int EPI>
-__global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uint4 *wp, const int64_t *ids,
-                                                      const bf16_t *nw, int ldx, int K, int N, int M, int tiles_per_wg,
-                                                      int id_rows, float eps, int dbg, const LinTail tl) {
+__global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uint4 *wp, const int64_t *ids, int ldx, int K,
+                                                      int N, int M, int tiles_per_wg, int dbg, int id_rows,
+                                                      const bf16_t *nw, float eps, const LinTail tl) {
+    // argument order: the 14 dwords the hardware preloads into SGPRs are the ones the first loads need
+    QTTS_TRACE(0);
     LinArgs p;
     p.x = x; p.ldx = ldx; p.ids = ids; p.id_rows = id_rows; p.wp = wp; p.bias = tl.bias; p.res = tl.res; p.ldr = tl.ldr;
     p.nw = nw; p.eps = eps; p.xnorm_out = tl.xnorm_out; p.ldxn = tl.ldxn; p.out = tl.out; p.ldo = tl.ldo;
@@ -204,26 +211,25 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     const int t_begin = bx * p.tiles_per_wg;
     const int t_end = min(t_begin + p.tiles_per_wg, ntiles);
 
-    // ---- activation prologue
+    // ---- activation prologue.  Rows beyond M read row 0 instead of being predicated off: their MFMA columns
+    // are never stored, and unconditional loads keep the instruction stream ahead of the weight requests short.
     Frag xb[KSW];
     size_t xrow = 0;
-    if (mvalid) {
-        long rid = m;
+    {
+        long rid = mvalid ? m : 0;
         if (p.ids) {
-            rid = p.ids[m];
+            rid = p.ids[rid];
             rid = rid < 0 ? 0 : (rid >= p.id_rows ? p.id_rows - 1 : rid);
         }
         xrow = (size_t)rid * p.ldx;
     }
+    const bf16_t *xp = p.x + xrow + 32 * ks0 + 8 * g;
 #pragma unroll
     for (int i = 0; i < KSW; ++i) {
-        const int k = 32 * (ks0 + i) + 8 * g;
-        if (!mvalid || (p.dbg & 2)) {
-            xb[i].u = make_uint4(0, 0, 0, 0);
-        } else if (PRO == 2) {
+        if (PRO == 2) {
             Frag ga, up;
-            ga.u = *reinterpret_cast<const uint4 *>(p.x + xrow + k);
-            up.u = *reinterpret_cast<const uint4 *>(p.x + xrow + p.K + k);
+            ga.u = *reinterpret_cast<const uint4 *>(xp + 32 * i);
+            up.u = *reinterpret_cast<const uint4 *>(xp + p.K + 32 * i);
             uint32_t gw[4] = {ga.u.x, ga.u.y, ga.u.z, ga.u.w}, uw[4] = {up.u.x, up.u.y, up.u.z, up.u.w}, ow[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             }
             xb[i].u = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         } else {
-            xb[i].u = *reinterpret_cast<const uint4 *>(p.x + xrow + k);
+            xb[i].u = *reinterpret_cast<const uint4 *>(xp + 32 * i);
         }
     }
     // The (small) activation loads above go out first: vector memory requests of a wave are served in order, so
@@ -311,7 +317,9 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[DB ? cur : 0][i].v, xb[i].v, acc, 0, 0, 0);
         float4_t *red = smem4 + (size_t)(it & 1) * NW * 64;
         red[wave * 64 + lane] = acc;
+        QTTS_TRACE(1);
         __syncthreads();
+        QTTS_TRACE(2);
         if (wave == 0) {
             float4_t sum = red[lane];
             for (int w = 1; w < NW; ++w) sum += red[w * 64 + lane];
@@ -355,6 +363,12 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             }
         }
     };
+    if (!DB) {
+        // one tile per workgroup: straight-line code, every load of the launch is in flight before the first wait
+        tile_body(0, t_begin, 0);
+        QTTS_TRACE(3);
+        return;
+    }
     int it = 0;
     for (int t = t_begin; t < t_end; t += 2, it += 2) {
         tile_body(0, t, it);
@@ -367,8 +381,13 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
     size_t shmem = (size_t)2 * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
     LinTail tl;
     tl.bias = a.bias; tl.res = a.res; tl.ldr = a.ldr; tl.xnorm_out = a.xnorm_out; tl.ldxn = a.ldxn; tl.out = a.out; tl.ldo = a.ldo;
-    hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids, a.nw, a.ldx,
-                       a.K, a.N, a.M, a.tiles_per_wg, a.id_rows, a.eps, a.dbg, tl);
+    tl.trace = nullptr;
+    if (g_trace) {
+        tl.trace = g_trace + (size_t)g_trace_launch * 4 * 1024;      // up to 1024 workgroups per traced launch
+        ++g_trace_launch;
+    }
+    hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids, a.ldx,
+                       a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
 }
 
 static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = false) {
@@ -393,13 +412,13 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     QCHECK(!(pro == 1 && KSW == 24), "linear: RMSNorm prologue not supported for K=%d", a.K);
     const int NW = KS / KSW;
     const int ntiles = a.N / 16;
-    const bool db = KSW <= 12;
     int tpw = 1;
-    if (db) {
+    if (KSW <= 12) {
         const int target = g_tune_t > 0 ? g_tune_t * 64 : 256;
         tpw = (ntiles + target - 1) / target;
     }
-    if (silu_pairs) QCHECK(db, "linear: the SwiGLU epilogue needs K <= 3072 (K=%d)", a.K);
+    const bool db = tpw > 1;                              // tile loop with a register double buffer
+    if (silu_pairs) QCHECK(KSW <= 12, "linear: the SwiGLU epilogue needs K <= 3072 (K=%d)", a.K);
     a.tiles_per_wg = tpw;
     a.dbg = g_dbg_linear;
     const int gx = (ntiles + tpw - 1) / tpw, gy = (a.M + 15) / 16;
@@ -408,18 +427,22 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
         a.dbg |= gy << 8;                                  // row-tile count rides above the experiment bits
         grid = dim3(((gx + 7) / 8) * 8 * gy, 1);
     }
-#define QL2(KSW_, DB_) case KSW_: \
-        if (silu_pairs && DB_) { if (pro == 1) launch_linear2_inst<KSW_, 1, DB_, DB_ ? 1 : 0>(grid, NW, s, a); \
-                                 else launch_linear2_inst<KSW_, 0, DB_, DB_ ? 1 : 0>(grid, NW, s, a); } \
+#define QL2D(KSW_, DB_) \
+        if (silu_pairs) { if (pro == 1) launch_linear2_inst<KSW_, 1, DB_, 1>(grid, NW, s, a); \
+                          else launch_linear2_inst<KSW_, 0, DB_, 1>(grid, NW, s, a); } \
         else if (pro == 0) launch_linear2_inst<KSW_, 0, DB_, 0>(grid, NW, s, a); \
         else if (pro == 1) launch_linear2_inst<KSW_, 1, DB_, 0>(grid, NW, s, a); \
-        else launch_linear2_inst<KSW_, 2, DB_, 0>(grid, NW, s, a); \
-        break;
+        else launch_linear2_inst<KSW_, 2, DB_, 0>(grid, NW, s, a);
+#define QL2(KSW_) case KSW_: if (db) { QL2D(KSW_, true) } else { QL2D(KSW_, false) } break;
     switch (KSW) {
-        QL2(1, true) QL2(2, true) QL2(4, true) QL2(6, true) QL2(8, true) QL2(12, true) QL2(24, false)
+        QL2(1) QL2(2) QL2(4) QL2(6) QL2(8) QL2(12)
+        case 24: if (pro == 0) launch_linear2_inst<24, 0, false, 0>(grid, NW, s, a);
+                 else launch_linear2_inst<24, 2, false, 0>(grid, NW, s, a);
+                 break;
         default: QFAIL(QTTS_EINVAL, "linear: unsupported KSW %d", KSW);
     }
 #undef QL2
+#undef QL2D
     QLAUNCH();
     return QTTS_OK;
 }

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libqtts_hip.so")
+LIB_PATH = os.environ.get("QTTS_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libqtts_hip.so")   # QTTS_LIB: A/B builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -67,6 +67,7 @@ _SIGS = {
     "qtts_graph_destroy": (None, [_p]),
     "qtts_tune_linear": (None, [_i, _i]),
     "qtts_debug_linear": (None, [_i]),
+    "qtts_debug_linear_trace": (None, [_p]),
     "qtts_debug_grid_barrier": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
 }
 for _name, (_res, _args) in _SIGS.items():
@@ -74,7 +75,7 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-EXPORTED = [n for n in _SIGS if n not in ("qtts_tune_linear", "qtts_debug_linear", "qtts_debug_grid_barrier")]
+EXPORTED = [n for n in _SIGS if n not in ("qtts_tune_linear", "qtts_debug_linear", "qtts_debug_linear_trace", "qtts_debug_grid_barrier")]
 
 
 class QttsError(RuntimeError):

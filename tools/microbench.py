@@ -143,9 +143,12 @@ def lat():
     B = 8
     shapes = [("o pred", 1024, 2048, "res"), ("down pred", 1024, 3072, "res"), ("qkv pred", 4096, 1024, "norm"),
               ("head pred", 2048, 1024, "norm"), ("o 1.7B", 2048, 2048, "res"), ("qkv 1.7B", 4096, 2048, "norm")]
+    hot = os.environ.get("QTTS_LAT_HOT") == "1"           # one weight buffer replayed: it stays in L2 / Infinity Cache
     for name, N, K, kind in shapes:
         nbuf = max(2, int(600e6 // (N * K * 2)))
-        ws = [torch.randn(N * K, device=dev).bfloat16() * 0.02 for _ in range(nbuf)]
+        ws = [torch.randn(N * K, device=dev).bfloat16() * 0.02 for _ in range(1 if hot else nbuf)]
+        if hot:
+            ws = ws * nbuf
         x = torch.randn(B, K, device=dev).bfloat16()
         nw = torch.ones(K, device=dev).bfloat16()
         out = torch.empty(B, N, dtype=torch.bfloat16, device=dev)
@@ -155,7 +158,7 @@ def lat():
         def run():
             for w in ws:
                 hip.linear_fused(x, w, N, K=K, norm_w=nw if kind == "norm" else None, residual=res if kind != "norm" else None, out=out)
-        for flags in (0, 1, 2, 3):
+        for flags in (0, 2):
             hip.lib.qtts_debug_linear(flags)
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
@@ -165,6 +168,45 @@ def lat():
             line += f"  dbg{flags}: {us:5.2f}us"
         hip.lib.qtts_debug_linear(0)
         print(line, flush=True)
+
+
+def trace():
+    """Timestamps inside back-to-back GEMM launches of one graph (100 MHz device clock): when the first workgroup
+    starts, when its operands have arrived and been multiplied, when the reduction barrier opens, when the last
+    workgroup ends, and the gap to the next launch."""
+    import numpy as np
+    B, NL = 8, 40
+    for name, N, K, kind in (("o pred", 1024, 2048, "res"), ("qkv pred", 4096, 1024, "norm"), ("down pred", 1024, 3072, "res"),
+                             ("o 1.7B", 2048, 2048, "res")):
+        ws = [torch.randn(N * K, device=dev).bfloat16() * 0.02 for _ in range(NL)]
+        x = torch.randn(B, K, device=dev).bfloat16()
+        nw = torch.ones(K, device=dev).bfloat16()
+        out = torch.empty(B, N, dtype=torch.bfloat16, device=dev)
+        res = torch.randn(B, N, device=dev).bfloat16()
+        buf = torch.zeros(NL * 1024 * 4, dtype=torch.int64, device=dev)
+
+        def run():
+            for w in ws:
+                hip.linear_fused(x, w, N, K=K, norm_w=nw if kind == "norm" else None, residual=res if kind != "norm" else None, out=out)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            run()
+            hip.lib.qtts_debug_linear_trace(hip.ptr(buf))
+            gr = hip.Graph.capture(run)
+            hip.lib.qtts_debug_linear_trace(None)
+            for _ in range(3):
+                gr.launch()
+            st.synchronize()
+        t = buf.cpu().numpy().reshape(NL, 1024, 4).astype(np.float64) * 10.0      # ns
+        nwg = int((t[0, :, 0] > 0).sum())
+        t = t[:, :nwg]
+        first_start, last_start = t[:, :, 0].min(1), t[:, :, 0].max(1)
+        mfma_done, bar_open, end = t[:, :, 1].max(1), t[:, :, 2].max(1), t[:, :, 3].max(1)
+        gap = first_start[1:] - end[:-1]
+        med = lambda a: float(np.median(a))
+        print(f"{name:10s} {nwg:4d} WGs: launch-to-launch {med(np.diff(first_start)):7.0f} ns | gap end->next start {med(gap):6.0f} | "
+              f"start spread {med(last_start - first_start):5.0f} | first start -> last MFMA done {med(mfma_done - first_start):6.0f} | "
+              f"-> barrier open {med(bar_open - first_start):6.0f} | -> last end {med(end - first_start):6.0f}", flush=True)
 
 
 def gridbar():
@@ -229,6 +271,7 @@ def frame():
     def burst_body():
         pr._burst_body(B)
 
+    hip.lib.qtts_debug_linear(int(os.environ.get("QTTS_LINEAR_DBG", "0")))
     only = os.environ.get("QTTS_FRAME_ONLY")
     for name, body, nk in (("talker 28 layers", talker_body, 1), ("predictor burst", burst_body, 1),
                            ("whole frame", lambda: fe._frame_body(B, 256), 1)):
@@ -242,4 +285,4 @@ def frame():
 
 
 if __name__ == "__main__":
-    {"launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar}[sys.argv[1]]()
+    {"launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
