@@ -129,7 +129,9 @@ extern "C" int qtts_pack_gate_up(const void *gate, const void *up, void *packed,
 static int g_tune_ksw = 0;   // 0 = automatic
 static int g_tune_t = 0;
 static int g_dbg_linear = 0;
+static int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
 extern "C" void qtts_tune_linear(int ksw, int t) { g_tune_ksw = ksw; g_tune_t = t; }
+extern "C" void qtts_tune_subtiles(int min_bytes) { g_sub_min_bytes = min_bytes; }
 extern "C" void qtts_debug_linear(int flags) { g_dbg_linear = flags; }
 static long long *g_trace = nullptr;       // tuning experiments only: timestamp buffer of traced GEMM launches
 static int g_trace_launch = 0;
@@ -177,7 +179,7 @@ struct LinTail {
 };
 #define QTTS_TRACE(slot) do { if (tl.trace && threadIdx.x == 0) tl.trace[(size_t)blockIdx.x * 4 + (slot)] = wall_clock64(); } while (0)
 
-template <int KSW, int PRO, bool DB, int EPI>
+template <int KSW, int PRO, bool DB, int EPI, bool SUB = false>
 __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uint4 *wp, const int64_t *ids, int ldx, int K,
                                                       int N, int M, int tiles_per_wg, int dbg, int id_rows,
                                                       const bf16_t *nw, float eps, const LinTail tl) {
@@ -204,6 +206,14 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         by = rem >> 3;
         if (bx * p.tiles_per_wg >= (p.N >> 4)) return;
     }
+    // Narrow outputs with a long K (fewer tiles than CUs, a large slice per workgroup): a 16-row weight tile is
+    // shared by 2 or 4 workgroups, each loading and storing only its 8 or 4 rows (the other A rows are zero), so
+    // that more CUs stream a share of the matrix.
+    const int ssh = SUB ? (p.dbg >> 4) & 3 : 0;            // log2 of the workgroups per tile (single-tile launches only)
+    const int sub = bx & ((1 << ssh) - 1);
+    bx >>= ssh;
+    const bool arow = !SUB || (r >> (4 - ssh)) == sub;      // this lane's weight row belongs to the workgroup
+    const bool orow = !SUB || (g >> (2 - ssh)) == sub;      // this lane's four output columns do
     const int m = by * 16 + r;
     const bool mvalid = m < p.M;
     const int ks0 = wave * KSW;
@@ -250,7 +260,10 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     {
         const uint4 *wptr = p.wp + ((size_t)((p.dbg & 1) ? 0 : t_begin) * KS + ks0) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < KSW; ++i) a[0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
+        for (int i = 0; i < KSW; ++i) {
+            if (arow) a[0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
+            else a[0][i].u = make_uint4(0, 0, 0, 0);
+        }
     }
 
     float *normred = reinterpret_cast<float *>(smem4 + (size_t)2 * NW * 64);
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
                 o4[j] = pack2(rbf(v0 * rstd) * w0, rbf(v1 * rstd) * w1);
             }
             xb[i].u = make_uint4(o4[0], o4[1], o4[2], o4[3]);
-            if (p.xnorm_out && bx == 0 && mvalid)
+            if (p.xnorm_out && bx == 0 && sub == 0 && mvalid)
                 *reinterpret_cast<uint4 *>(p.xnorm_out + (size_t)m * p.ldxn + k) = xb[i].u;
         }
     }
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         // residual / bias words of this tile are requested up front by the wave that will need them, so the
         // epilogue does not start another memory round trip after the reduction
         uint2 resw = make_uint2(0, 0), biasw = make_uint2(0, 0);
-        if (EPI == 0 && wave == 0) {
+        if (EPI == 0 && wave == 0 && orow) {
             if (p.res && mvalid) resw = *reinterpret_cast<const uint2 *>(p.res + (size_t)m * p.ldr + 16 * t + 4 * g);
             if (p.bias) biasw = *reinterpret_cast<const uint2 *>(p.bias + 16 * t + 4 * g);
         }
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
                 return;
             }
             const int n = 16 * t + 4 * g;
-            if (mvalid) {
+            if (mvalid && orow) {
                 uint32_t o2[2];
                 float v[4], rf[4], bfv[4];
                 unpack2(resw.x, rf[0], rf[1]);
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     }
 }
 
-template <int KSW, int PRO, bool DB, int EPI>
+template <int KSW, int PRO, bool DB, int EPI, bool SUB = false>
 static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs &a) {
     size_t shmem = (size_t)2 * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
     LinTail tl;
@@ -386,7 +399,7 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
         tl.trace = g_trace + (size_t)g_trace_launch * 4 * 1024;      // up to 1024 workgroups per traced launch
         ++g_trace_launch;
     }
-    hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids, a.ldx,
+    hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI, SUB>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids, a.ldx,
                        a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
 }
 
@@ -421,7 +434,15 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     if (silu_pairs) QCHECK(KSW <= 12, "linear: the SwiGLU epilogue needs K <= 3072 (K=%d)", a.K);
     a.tiles_per_wg = tpw;
     a.dbg = g_dbg_linear;
-    const int gx = (ntiles + tpw - 1) / tpw, gy = (a.M + 15) / 16;
+    int gx = (ntiles + tpw - 1) / tpw;
+    const int gy = (a.M + 15) / 16;
+    int ssh = 0;
+    if (tpw == 1 && gy == 1 && !silu_pairs && pro != 2) {
+        // 2 or 4 workgroups per tile while not every CU has one and a workgroup's slice stays above the threshold
+        while (ssh < 2 && (gx << (ssh + 1)) <= 256 && ((a.K * 32) >> (ssh + 1)) >= g_sub_min_bytes) ++ssh;
+        a.dbg |= ssh << 4;
+        gx <<= ssh;
+    }
     dim3 grid(gx, 1);
     if (gy > 1) {
         a.dbg |= gy << 8;                                  // row-tile count rides above the experiment bits
@@ -433,15 +454,19 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
         else if (pro == 0) launch_linear2_inst<KSW_, 0, DB_, 0>(grid, NW, s, a); \
         else if (pro == 1) launch_linear2_inst<KSW_, 1, DB_, 0>(grid, NW, s, a); \
         else launch_linear2_inst<KSW_, 2, DB_, 0>(grid, NW, s, a);
-#define QL2(KSW_) case KSW_: if (db) { QL2D(KSW_, true) } else { QL2D(KSW_, false) } break;
+#define QL2S(KSW_) if (pro == 0) launch_linear2_inst<KSW_, 0, false, 0, true>(grid, NW, s, a); \
+                   else launch_linear2_inst<KSW_, 1, false, 0, true>(grid, NW, s, a);
+#define QL2(KSW_) case KSW_: if (ssh) { QL2S(KSW_) } else if (db) { QL2D(KSW_, true) } else { QL2D(KSW_, false) } break;
     switch (KSW) {
         QL2(1) QL2(2) QL2(4) QL2(6) QL2(8) QL2(12)
-        case 24: if (pro == 0) launch_linear2_inst<24, 0, false, 0>(grid, NW, s, a);
-                 else launch_linear2_inst<24, 2, false, 0>(grid, NW, s, a);
+        case 24: if (ssh) launch_linear2_inst<24, 0, false, 0, true>(grid, NW, s, a);
+                 else if (pro == 0) launch_linear2_inst<24, 0, false, 0>(grid, NW, s, a);
+                 else QFAIL(QTTS_EINVAL, "linear: activation prologues are not supported for K=%d", a.K);
                  break;
         default: QFAIL(QTTS_EINVAL, "linear: unsupported KSW %d", KSW);
     }
 #undef QL2
+#undef QL2S
 #undef QL2D
     QLAUNCH();
     return QTTS_OK;

@@ -272,6 +272,7 @@ def frame():
         pr._burst_body(B)
 
     hip.lib.qtts_debug_linear(int(os.environ.get("QTTS_LINEAR_DBG", "0")))
+    hip.lib.qtts_tune_subtiles(int(os.environ.get("QTTS_SUBTILE_MIN", str(32 << 10))))
     only = os.environ.get("QTTS_FRAME_ONLY")
     for name, body, nk in (("talker 28 layers", talker_body, 1), ("predictor burst", burst_body, 1),
                            ("whole frame", lambda: fe._frame_body(B, 256), 1)):
