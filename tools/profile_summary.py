@@ -12,7 +12,7 @@ import os
 import statistics
 import sys
 
-DOMINANT = "linear2_kernel<8, 1, true, 1>"
+DOMINANT = "linear2_kernel<8, 1, true, 1,"
 
 
 def main():
