@@ -30,14 +30,15 @@ def main():
         name = k.replace("void ", "")[:60]
         lines.append(f"{name:60s} calls {len(v):6d} avg {statistics.mean(v) / 1e3:8.2f} us  total {sum(v) / 1e6:8.2f} ms "
                      f"{100 * sum(v) / total:5.1f}%")
-    lines += ["", f"{DOMINANT} by grid (x = workgroups*512 threads, y = 16-row tiles of the activation):"]
+    lines += ["", f"{DOMINANT} by grid (x = workgroups*512 threads; prefill launches carry one workgroup per row tile and weight tile):"]
     by = collections.defaultdict(list)
     for r in rows:
         if DOMINANT in r["Kernel_Name"]:
             by[(int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]))].append(dur(r))
+    smallest = min(by) if by else None
     for k, v in sorted(by.items()):
         lines.append(f"  grid {k}: calls {len(v):5d} avg {statistics.mean(v) / 1e3:7.2f} us  median {statistics.median(v) / 1e3:7.2f} us"
-                     f"  min {min(v) / 1e3:7.2f} us" + ("   <- the decode launch bench.py times" if k[1] == 1 else "   (prefill)"))
+                     f"  min {min(v) / 1e3:7.2f} us" + ("   <- the decode launch bench.py times" if k == smallest else "   (prefill: several row tiles)"))
     # one steady-state frame: from one predictor_input launch to the next
     idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("predictor_input_kernel")]
     if len(idx) > 3:
