@@ -433,6 +433,9 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
         // the predictor's gate/up GEMM: 6.9 -> 6.7 us); beyond that the tile loop with its double buffer wins
         if (g_tune_t == 0 && ntiles <= 384) tpw = 1;
     }
+    // prefill (several row tiles): single-tile workgroups keep the register count low, so that three or four
+    // workgroups share a CU and cover each other's memory latency
+    if (a.M > 16) tpw = 1;
     const bool db = tpw > 1;                              // tile loop with a register double buffer
     if (silu_pairs) QCHECK(KSW <= 12, "linear: the SwiGLU epilogue needs K <= 3072 (K=%d)", a.K);
     a.tiles_per_wg = tpw;
@@ -1491,7 +1494,7 @@ extern "C" int qtts_model_set_kv_cache(qtts_model_t *m, void *kv, int num_blocks
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t qkv, attn, act, xa, xb, att_ws, att_cnt, total;
+    size_t qkv, attn, act, xa, xb, xn, att_ws, att_cnt, total;
 };
 
 static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
@@ -1503,6 +1506,7 @@ static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
     L.act = off; off += align256((size_t)rows * m->inter * 2);
     L.xa = off; off += align256((size_t)rows * m->hidden * 2);
     L.xb = off; off += align256((size_t)rows * m->hidden * 2);
+    L.xn = off; off += align256((size_t)rows * m->hidden * 2);       // normalised rows of a prompt (prefill GEMMs)
     // prefill and decode attention share the partials region; the decode kernel's arrival counters follow it
     const size_t pre = qtts_attn_workspace_bytes(rows, m->n_heads, max_context);
     const size_t dec = attn2_partial_bytes(rows, m->n_heads, max_context);
@@ -1551,8 +1555,13 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     bf16_t *act = (bf16_t *)(m->ws + W.act);
     bf16_t *xa = (bf16_t *)(m->ws + W.xa);
     bf16_t *xb = (bf16_t *)(m->ws + W.xb);
+    bf16_t *xn = (bf16_t *)(m->ws + W.xn);
     void *att_ws = m->ws + W.att_ws;
     const int H = m->hidden, Hq = m->n_heads, Hkv = m->n_kv_heads;
+    // More than one 16-row tile (prefill): the rows are normalised by their own launch and the GEMMs run without
+    // the norm prologue, whose registers would leave room for one workgroup per CU only; up to 16 rows the norm
+    // rides in the GEMM prologue.
+    const bool split_norm = N > 16;
     const int qkvw = (Hq + 2 * Hkv) * 128;
     const float scale = 1.0f / sqrtf((float)m->head_dim);
     const size_t layer_kv = (size_t)m->num_blocks * QTTS_KV_BLOCK * Hkv * 128 * 2;   // bytes per layer per K or V
@@ -1563,8 +1572,12 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         const LayerW &L = m->layers[l];
         char *kc = m->kv + (size_t)l * layer_kv;
         char *vc = m->kv + ((size_t)m->n_layers + l) * layer_kv;
-        if ((rc = qtts_linear_fused(cur, H, nullptr, 0, L.wqkv, nullptr, nullptr, 0, L.in_norm, m->eps, nullptr, 0, 0,
-                                    qkv, qkvw, N, qkvw, H, stream))) return rc;
+        if (split_norm) {
+            if ((rc = qtts_rmsnorm(cur, H, L.in_norm, m->eps, xn, H, N, H, stream))) return rc;
+            if ((rc = qtts_linear_fused(xn, H, nullptr, 0, L.wqkv, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, 0,
+                                        qkv, qkvw, N, qkvw, H, stream))) return rc;
+        } else if ((rc = qtts_linear_fused(cur, H, nullptr, 0, L.wqkv, nullptr, nullptr, 0, L.in_norm, m->eps, nullptr, 0, 0,
+                                           qkv, qkvw, N, qkvw, H, stream))) return rc;
         if (decode) {
             if ((rc = attention_decode_fused_impl(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
                                                   positions, slot_mapping, kc, vc, block_tables, max_blocks,
@@ -1578,7 +1591,10 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         }
         if ((rc = qtts_linear_fused(attn, Hq * 128, nullptr, 0, L.wo, nullptr, cur, H, nullptr, 0.f, nullptr, 0, 0, xa, H,
                                     N, H, Hq * 128, stream))) return rc;
-        if ((rc = qtts_linear_swiglu(xa, H, L.wgu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
+        if (split_norm) {
+            if ((rc = qtts_rmsnorm(xa, H, L.post_norm, m->eps, xn, H, N, H, stream))) return rc;
+            if ((rc = qtts_linear_swiglu(xn, H, L.wgu, nullptr, 0.f, act, m->inter, N, m->inter, H, stream))) return rc;
+        } else if ((rc = qtts_linear_swiglu(xa, H, L.wgu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
         if ((rc = qtts_linear_fused(act, m->inter, nullptr, 0, L.wdown, nullptr, xa, H, nullptr, 0.f, nullptr, 0, 0,
                                     xb, H, N, H, m->inter, stream))) return rc;
         // Fixed roles: xa = post-attention residual stream, xb = layer output.  The next layer reads xb
@@ -1586,6 +1602,11 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         cur = xb;
     }
     if (head_w) {
+        if (split_norm) {
+            if ((rc = qtts_rmsnorm(cur, H, m->final_norm, m->eps, hidden_out, H, N, H, stream))) return rc;
+            return qtts_linear_fused(hidden_out, H, nullptr, 0, head_w, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, 0,
+                                     logits_out, vocab, N, vocab, H, stream);
+        }
         // final RMSNorm folded into the head GEMM's prologue; the normalised rows are the returned hidden state
         if ((rc = qtts_linear_fused(cur, H, nullptr, 0, head_w, nullptr, nullptr, 0, m->final_norm, m->eps, hidden_out, H, 0,
                                     logits_out, vocab, N, vocab, H, stream))) return rc;
