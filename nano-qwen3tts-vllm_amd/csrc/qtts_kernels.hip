@@ -874,9 +874,9 @@ __device__ __forceinline__ void st_agent(float *p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int G, int NG>
+template <int G, int NG, int TPG = ATT2_SPLIT / NG>
 __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFusedArgs p) {
-    constexpr int TPG = ATT2_SPLIT / NG;               // tokens a 16-lane group walks
+    constexpr int SPLIT = NG * TPG;                    // tokens per workgroup; TPG = tokens a 16-lane group walks
     constexpr int NT = NG * 16;
     __shared__ float sm_acc[NG][G][128];
     __shared__ float sm_m[NG][G];
@@ -885,14 +885,14 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
     const int row = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
     const int ctx = p.context_lens[row];
     const int Hq = p.Hq, Hkv = p.Hkv;
-    const int t0 = split * ATT2_SPLIT;
+    const int t0 = split * SPLIT;
     if (ctx <= 0) {
         if (split == 0)
             for (int e = threadIdx.x; e < G * 128; e += NT) p.out[(size_t)row * p.ldo + (size_t)kvh * G * 128 + e] = 0;
         return;
     }
     if (t0 >= ctx) return;
-    const int nact = (ctx + ATT2_SPLIT - 1) / ATT2_SPLIT;   // splits of this row that hold tokens
+    const int nact = (ctx + SPLIT - 1) / SPLIT;   // splits of this row that hold tokens
     const int32_t *bt = p.block_tables + (size_t)row * p.max_blocks;
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const bf16_t *rowp = p.qkv + (size_t)row * p.ld;
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
 #pragma unroll
         for (int j = 0; j < 8; ++j) knew.h[j] = f2bf(kn[j]);
         const int slot = p.slots ? p.slots[row] : -1;
-        if (slot >= 0 && grp == 0 && (ctx - 1) >= t0 && (ctx - 1) < t0 + ATT2_SPLIT) {
+        if (slot >= 0 && grp == 0 && (ctx - 1) >= t0 && (ctx - 1) < t0 + SPLIT) {
             const size_t off = ((size_t)slot * Hkv + kvh) * 128 + 8 * l16;
             *reinterpret_cast<uint4 *>(p.kc + off) = knew.u;
             *reinterpret_cast<uint4 *>(p.vc + off) = vnew.u;
@@ -1076,8 +1076,15 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
                ldo >= Hq * 128, "attention_decode_fused: bad shape");
     QCHECK(max_pos > 0 && max_blocks > 0 && max_context > 0 && max_context <= max_blocks * QTTS_KV_BLOCK,
            "attention_decode_fused: bad context bounds");
-    const int ns = attn2_nsplit(max_context);
-    QCHECK(ns == 1 || (partials && counters), "attention_decode_fused: workspace required for contexts > %d", ATT2_SPLIT);
+    // 128-token workgroups, except where 256-token ones (eight tokens per 16-lane group) pay: contexts of 129..256,
+    // which then finish without the cross-workgroup merge (talker layer stack 1217 -> 1197 us at 200 tokens), and
+    // launches whose 128-token workgroups would outnumber the 256 CUs (1459 -> 1392 us at 900 tokens; in between the
+    // narrower split is 2-3 % faster)
+    const int ns128 = (max_context + ATT2_SPLIT - 1) / ATT2_SPLIT;
+    const bool wide = Hq / Hkv <= 2 && ns128 > 1 && (ns128 == 2 || (long)B * Hkv * ns128 > 256);
+    const int split = wide ? 2 * ATT2_SPLIT : ATT2_SPLIT;
+    const int ns = (max_context + split - 1) / split;
+    QCHECK(ns == 1 || (partials && counters), "attention_decode_fused: workspace required for contexts > %d", split);
     AttnFusedArgs a;
     a.qkv = (const bf16_t *)qkv; a.ld = ldqkv; a.qw = (const bf16_t *)q_norm_w; a.kw = (const bf16_t *)k_norm_w; a.eps = eps;
     a.cosT = (const bf16_t *)rope_cos; a.sinT = (const bf16_t *)rope_sin; a.max_pos = max_pos; a.positions = positions; a.slots = slot_mapping;
@@ -1089,9 +1096,11 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
     switch (Hq / Hkv) {
         // short contexts (the code predictor's 17 tokens) leave most of a 32-group workgroup idle
         case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 16>), grid, dim3(256), 0, s, a);
+                else if (wide) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32, 8>), grid, dim3(512), 0, s, a);
                 else hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32>), grid, dim3(512), 0, s, a);
                 break;
         case 2: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 16>), grid, dim3(256), 0, s, a);
+                else if (wide) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 32, 8>), grid, dim3(512), 0, s, a);
                 else hipLaunchKernelGGL((attn_decode_fused_kernel<2, 32>), grid, dim3(512), 0, s, a);
                 break;
         case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<4, 16>), grid, dim3(256), 0, s, a); break;
@@ -1117,7 +1126,7 @@ extern "C" int qtts_attention_decode_fused(const void *qkv, int ldqkv, const voi
     if (workspace && B > 0 && Hq > 0 && Hkv > 0 && max_context > 0) {
         // the arrival counters sit behind the partials and must be zero when the kernel starts
         counters = (int *)((char *)workspace + attn2_partial_bytes(B, Hq, max_context));
-        if (attn2_nsplit(max_context) > 1) {
+        if (max_context > ATT2_SPLIT) {
             hipError_t e = hipMemsetAsync(counters, 0, (size_t)B * Hkv * sizeof(int), s);
             if (e != hipSuccess) QFAIL((int)e, "attention_decode_fused: memset failed: %s", hipGetErrorString(e));
         }

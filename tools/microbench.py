@@ -257,16 +257,18 @@ def frame():
     fe = FrameEngine(d, max_streams=B, max_text_frames=64, talker_weights=tw, predictor_weights=pw,
                      num_kvcache_blocks=4 * B, max_num_batched_tokens=4096, codec_eos=None)
     sp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
+    plen = int(os.environ.get("QTTS_FRAME_PROMPT", "100"))
     for i in range(B):
-        fe.add_stream(torch.randn(100, 2048, device=dev) * 0.5, torch.randn(8, 2048, device=dev) * 0.1, 60, sp,
+        fe.add_stream(torch.randn(plen, 2048, device=dev) * 0.5, torch.randn(8, 2048, device=dev) * 0.1, 60, sp,
                       SamplingParams(temperature=0.9, max_tokens=17, do_sample=False))
     fe.run_frames(3)
     tr, pr = fe.tr, fe.pr
+    mctx = (plen + 4 + 127) // 128 * 128
     st, mb = tr.dstage, tr.max_blocks_per_seq
 
     def talker_body():
         tr.decoder.forward(fe.next_x[:B], st.d("positions")[:B], st.d("slots")[:B], st.d("ctx")[:B],
-                           st.d("tables")[:B * mb].view(B, mb), 256, out=fe.cur_hidden[:B])
+                           st.d("tables")[:B * mb].view(B, mb), mctx, out=fe.cur_hidden[:B])
 
     def burst_body():
         pr._burst_body(B)
@@ -275,7 +277,7 @@ def frame():
     hip.lib.qtts_tune_subtiles(int(os.environ.get("QTTS_SUBTILE_MIN", str(32 << 10))))
     only = os.environ.get("QTTS_FRAME_ONLY")
     for name, body, nk in (("talker 28 layers", talker_body, 1), ("predictor burst", burst_body, 1),
-                           ("whole frame", lambda: fe._frame_body(B, 256), 1)):
+                           ("whole frame", lambda: fe._frame_body(B, mctx), 1)):
         if only and only not in name:
             continue
         with torch.cuda.stream(tr.stream):
