@@ -61,6 +61,17 @@ int qtts_linear(const void *x, int ldx, const void *w_packed, const void *bias,
                 const void *residual, int ldr, const void *norm_w, float eps,
                 void *out, int ldo, int M, int N, int K, qtts_stream_t stream);
 
+/* qtts_linear without the norm prologue, with scratch memory for prompts: when K is long
+ * (more than 12 x 256) and M > 16 the product is formed as K parts whose fp32 partial sums
+ * go through `workspace` (qtts_linear_workspace_bytes(M, N, K) bytes, 0 when not needed)
+ * before the same bias/residual epilogue.  Without a sufficient workspace the call
+ * computes the same result by the single-pass kernel.  Same call sites as qtts_linear
+ * (P/layers/linear.py:147-153 for down_proj over a prompt's rows). */
+size_t qtts_linear_workspace_bytes(int M, int N, int K);
+int qtts_linear_ws(const void *x, int ldx, const void *w_packed, const void *bias,
+                   const void *residual, int ldr, void *out, int ldo, int M, int N, int K,
+                   void *workspace, size_t workspace_bytes, qtts_stream_t stream);
+
 /* out[M,I] = silu(x@Wg^T) * (x@Wu^T) with the reference's two roundings
  * (P/models/qwen3_tts_share.py:131-135, P/layers/activation.py:11-13);
  * optional fused RMSNorm of x as above. */

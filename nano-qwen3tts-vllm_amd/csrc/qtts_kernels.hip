@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -389,6 +390,163 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     }
 }
 
+// ------------------------------------------------------------------ linear over several row tiles (prompts)
+// The same split-K workgroup, but the activations of TM 16-row tiles stay in registers while the workgroup
+// streams `tiles_per_wg` weight tiles past them (double-buffered): a weight fragment is multiplied into TM
+// accumulators, so a weight tile is fetched once per TM row tiles instead of once per row tile, and the
+// activations once per workgroup instead of once per weight tile.  EPI 0 / 1 as above; EPI 2 writes fp32 partial
+// sums of one K part (blockIdx.y) for linear_parts_kernel to finish — the long-K projection runs as K parts,
+// since TM x K/8 activation fragments per wave must fit the register file.
+struct RowsArgs {
+    const bf16_t *bias, *res; int ldr;
+    bf16_t *out; int ldo;
+    float *part; int mpad;       // EPI 2: part[kpart][mpad][N]
+    int rgroups, KS;             // row groups of TM tiles; k-steps of a whole packed weight tile
+};
+
+template <int KSW, int TM, int EPI>
+__global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const uint4 *wp, int ldx, int N, int M,
+                                                          int tiles_per_wg, const RowsArgs p) {
+    extern __shared__ float4_t smem4[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int NW = blockDim.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    // workgroups that stream the same weight tiles (one per row group) sit next to each other in dispatch order
+    // on one XCD (workgroup i runs on XCD i % 8): the tiles come from HBM once, the other groups hit that L2
+    const int per = 8 * p.rgroups, grp = blockIdx.x / per, rem = blockIdx.x % per;
+    const int bx = grp * 8 + (rem & 7), by = rem >> 3;
+    const int ntiles = N >> 4;
+    const int t_begin = bx * tiles_per_wg;
+    if (t_begin >= ntiles) return;
+    const int t_end = min(t_begin + tiles_per_wg, ntiles);
+    const int ks0 = blockIdx.y * (NW * KSW) + wave * KSW;
+
+    // rows beyond M read row 0: their accumulator columns are never stored
+    Frag xb[TM][KSW];
+    int mrow[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        mrow[i] = (by * TM + i) * 16 + r;
+        const bf16_t *xp = x + (size_t)(mrow[i] < M ? mrow[i] : 0) * ldx + 32 * ks0 + 8 * g;
+#pragma unroll
+        for (int k = 0; k < KSW; ++k) xb[i][k].u = *reinterpret_cast<const uint4 *>(xp + 32 * k);
+    }
+    Frag a[2][KSW];
+    {
+        const uint4 *wptr = wp + ((size_t)t_begin * p.KS + ks0) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < KSW; ++k) a[0][k].u = wptr[k * 64];
+    }
+    auto tile_body = [&](const int cur, const int t, const int it) {
+        uint2 resw = make_uint2(0, 0), biasw = make_uint2(0, 0);
+        if (EPI == 0 && wave < TM) {
+            const int m = (by * TM + wave) * 16 + r;
+            if (p.res && m < M) resw = *reinterpret_cast<const uint2 *>(p.res + (size_t)m * p.ldr + 16 * t + 4 * g);
+            if (p.bias) biasw = *reinterpret_cast<const uint2 *>(p.bias + 16 * t + 4 * g);
+        }
+        if (t + 1 < t_end) {
+            const uint4 *wptr = wp + ((size_t)(t + 1) * p.KS + ks0) * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < KSW; ++k) a[cur ^ 1][k].u = wptr[k * 64];
+        }
+        float4_t acc[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KSW; ++k)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][k].v, xb[i][k].v, acc[i], 0, 0, 0);
+        float4_t *red = smem4 + (size_t)(it & 1) * NW * TM * 64;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) red[(wave * TM + i) * 64 + lane] = acc[i];
+        __syncthreads();
+        if (wave >= TM) return;
+        // wave i finishes row tile i of this weight tile
+        const float4_t *mine = red + wave * 64;
+        const int m = (by * TM + wave) * 16 + r;
+        float4_t sum = mine[lane];
+        for (int w = 1; w < NW; ++w) sum += mine[w * TM * 64 + lane];
+        if (EPI == 2) {
+            if (m < M)
+                *reinterpret_cast<float4_t *>(p.part + ((size_t)blockIdx.y * p.mpad + m) * N + 16 * t + 4 * g) = sum;
+            return;
+        }
+        if (EPI == 1) {
+            if (g < 2) {                                  // lanes 0..31 hold gate rows; the up rows sit 32 lanes on
+                float4_t ups = mine[lane + 32];
+                for (int w = 1; w < NW; ++w) ups += mine[w * TM * 64 + lane + 32];
+                if (m < M) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float gv = rbf(sum[j]);
+                        const float sv = rbf(gv / (1.0f + expf(-gv)));
+                        v[j] = sv * rbf(ups[j]);
+                    }
+                    *reinterpret_cast<uint2 *>(p.out + (size_t)m * p.ldo + 8 * t + 4 * g) =
+                        make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                }
+            }
+            return;
+        }
+        if (m < M) {
+            float v[4], rf[4], bfv[4];
+            unpack2(resw.x, rf[0], rf[1]);
+            unpack2(resw.y, rf[2], rf[3]);
+            unpack2(biasw.x, bfv[0], bfv[1]);
+            unpack2(biasw.y, bfv[2], bfv[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float q = sum[j];
+                if (p.bias) q += bfv[j];
+                q = rbf(q);
+                if (p.res) q = q + rf[j];
+                v[j] = q;
+            }
+            *reinterpret_cast<uint2 *>(p.out + (size_t)m * p.ldo + 16 * t + 4 * g) =
+                make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+        }
+    };
+    int it = 0;
+    for (int t = t_begin; t < t_end; t += 2, it += 2) {
+        tile_body(0, t, it);
+        if (t + 1 < t_end) tile_body(1, t + 1, it + 1);
+    }
+}
+
+// Sum of the K parts + the bias/residual epilogue (same rounding points as the single-launch epilogue).
+__global__ __launch_bounds__(256) void linear_parts_kernel(const float *part, int kparts, int mpad, int M, int N,
+                                                           const bf16_t *bias, const bf16_t *res, int ldr, bf16_t *out, int ldo) {
+    const int n4 = N >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
+    float4_t sum = *reinterpret_cast<const float4_t *>(part + (size_t)m * N + n);
+    for (int k = 1; k < kparts; ++k) sum += *reinterpret_cast<const float4_t *>(part + ((size_t)k * mpad + m) * N + n);
+    float v[4], rf[4] = {0.f, 0.f, 0.f, 0.f}, bfv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (res) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(res + (size_t)m * ldr + n);
+        unpack2(w.x, rf[0], rf[1]);
+        unpack2(w.y, rf[2], rf[3]);
+    }
+    if (bias) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(bias + n);
+        unpack2(w.x, bfv[0], bfv[1]);
+        unpack2(w.y, bfv[2], bfv[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float q = sum[j];
+        if (bias) q += bfv[j];
+        q = rbf(q);
+        if (res) q = q + rf[j];
+        v[j] = q;
+    }
+    *reinterpret_cast<uint2 *>(out + (size_t)m * ldo + n) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+}
+
 template <int KSW, int PRO, bool DB, int EPI, bool SUB = false>
 static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs &a) {
     size_t shmem = (size_t)2 * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
@@ -403,7 +561,71 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
                        a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
 }
 
-static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = false) {
+template <int KSW, int TM, int EPI>
+static void launch_rows_inst(dim3 grid, hipStream_t s, const LinArgs &a, int tpw, const RowsArgs &r) {
+    const size_t shmem = (size_t)2 * 8 * TM * 64 * sizeof(float4_t);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_rows_kernel<KSW, TM, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        once = true;
+    }
+    hipLaunchKernelGGL((linear_rows_kernel<KSW, TM, EPI>), grid, dim3(512), shmem, s, a.x, a.wp, a.ldx, a.N, a.M, tpw, r);
+}
+
+// Bytes of fp32 scratch the K-split form of a prompt GEMM needs (0 when the GEMM runs in one part).
+static size_t linear_rows_scratch_bytes(int M, int N, int K) {
+    const int KS = K / 32;
+    if (M <= 16 || KS % 8 != 0 || KS / 8 <= 12) return 0;
+    return (size_t)(KS / 64) * M * N * sizeof(float);
+}
+
+// Prompt GEMM (more than one 16-row tile, plain activations).  Returns false when the shape is not covered and the
+// caller should take the single-tile path.
+static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch, size_t scratch_bytes, hipStream_t s) {
+    const int KS = a.K / 32;
+    if (KS % 8 != 0) return false;
+    int ksw = KS / 8, kparts = 1;
+    if (ksw > 12) {                                       // long K: parts of 8 k-steps per wave
+        if (ksw % 8 != 0 || silu_pairs) return false;
+        kparts = ksw / 8;
+        ksw = 8;
+        if (!scratch || scratch_bytes < (size_t)kparts * a.M * a.N * sizeof(float)) return false;
+    }
+    if (ksw != 4 && ksw != 8 && ksw != 12) return false;
+    if (ksw == 12 && silu_pairs) return false;
+    const int mtiles = (a.M + 15) / 16;
+    const int TM = (mtiles <= 2 || ksw == 12) ? 2 : 4;
+    RowsArgs r;
+    r.bias = a.bias; r.res = a.res; r.ldr = a.ldr; r.out = a.out; r.ldo = a.ldo;
+    r.part = scratch; r.mpad = a.M; r.rgroups = (mtiles + TM - 1) / TM; r.KS = KS;
+    const int ntiles = a.N / 16;
+    // one round of workgroups (a CU holds one): as many as fit in 256, each streaming `tpw` weight tiles
+    const int gx_max = std::max(1, 256 / (r.rgroups * kparts));
+    const int tpw = (ntiles + gx_max - 1) / gx_max;
+    const int gx = (ntiles + tpw - 1) / tpw;
+    dim3 grid(((gx + 7) / 8) * 8 * r.rgroups, kparts);
+    const int epi = kparts > 1 ? 2 : (silu_pairs ? 1 : 0);
+#define QR(KSW_, TM_, EPI_) launch_rows_inst<KSW_, TM_, EPI_>(grid, s, a, tpw, r)
+    if (ksw == 12) QR(12, 2, 0);
+    else if (ksw == 8) {
+        if (TM == 2) { if (epi == 0) QR(8, 2, 0); else if (epi == 1) QR(8, 2, 1); else QR(8, 2, 2); }
+        else { if (epi == 0) QR(8, 4, 0); else if (epi == 1) QR(8, 4, 1); else QR(8, 4, 2); }
+    } else {
+        if (TM == 2) { if (epi == 0) QR(4, 2, 0); else QR(4, 2, 1); }
+        else { if (epi == 0) QR(4, 4, 0); else QR(4, 4, 1); }
+    }
+#undef QR
+    if (kparts > 1) {
+        const long quads = (long)a.M * (a.N / 4);
+        hipLaunchKernelGGL(linear_parts_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, scratch, kparts, a.M,
+                           a.M, a.N, a.bias, a.res, a.ldr, a.out, a.ldo);
+    }
+    return true;
+}
+
+static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = false, float *scratch = nullptr,
+                          size_t scratch_bytes = 0) {
     QCHECK(a.x && a.wp && a.out, "linear: null pointer");
     QCHECK(a.M > 0 && a.N > 0 && a.K > 0, "linear: empty shape M=%d N=%d K=%d", a.M, a.N, a.K);
     QCHECK(a.N % 16 == 0 && a.K % 32 == 0, "linear: need N%%16==0 and K%%32==0 (N=%d K=%d)", a.N, a.K);
@@ -414,6 +636,10 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     QCHECK(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.wp & 15) == 0 && ((uintptr_t)a.out & 7) == 0, "linear: misaligned pointer");
     QCHECK(pro != 1 || a.nw, "linear: norm prologue without weight");
     QCHECK(!a.xnorm_out || (a.ldxn % 8 == 0 && a.ldxn >= a.K), "linear: bad xnorm_out stride");
+    if (a.M > 16 && pro == 0 && !a.ids && !(g_dbg_linear & 2) && launch_linear_rows(a, silu_pairs, scratch, scratch_bytes, s)) {
+        QLAUNCH();
+        return QTTS_OK;
+    }
     const int KS = a.K / 32;
     static const int ksws[] = {1, 2, 4, 6, 8, 12, 24};
     int KSW = 0;
@@ -490,6 +716,23 @@ extern "C" int qtts_linear_fused(const void *x, int ldx, const int64_t *gather_i
     a.nw = (const bf16_t *)norm_w; a.eps = eps; a.xnorm_out = (bf16_t *)xnorm_out; a.ldxn = ldxn;
     a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.tiles_per_wg = 1;
     return launch_linear2(a, swiglu_input ? 2 : (norm_w ? 1 : 0), (hipStream_t)stream);
+}
+
+extern "C" size_t qtts_linear_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0) return 0;
+    return linear_rows_scratch_bytes(M, N, K);
+}
+
+extern "C" int qtts_linear_ws(const void *x, int ldx, const void *w_packed, const void *bias, const void *residual, int ldr,
+                              void *out, int ldo, int M, int N, int K, void *workspace, size_t workspace_bytes,
+                              qtts_stream_t stream) {
+    QCHECK(!workspace || ((uintptr_t)workspace & 15) == 0, "linear_ws: workspace must be 16-byte aligned");
+    LinArgs a;
+    a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0;
+    a.wp = (const uint4 *)w_packed; a.bias = (const bf16_t *)bias; a.res = (const bf16_t *)residual; a.ldr = ldr;
+    a.nw = nullptr; a.eps = 0.f; a.xnorm_out = nullptr; a.ldxn = 0;
+    a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.tiles_per_wg = 1;
+    return launch_linear2(a, 0, (hipStream_t)stream, false, (float *)workspace, workspace_bytes);
 }
 
 extern "C" int qtts_linear(const void *x, int ldx, const void *w_packed, const void *bias, const void *residual,
@@ -1503,7 +1746,7 @@ extern "C" int qtts_model_set_kv_cache(qtts_model_t *m, void *kv, int num_blocks
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WsLayout {
-    size_t qkv, attn, act, xa, xb, xn, att_ws, att_cnt, total;
+    size_t qkv, attn, act, xa, xb, xn, parts, parts_bytes, att_ws, att_cnt, total;
 };
 
 static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
@@ -1516,6 +1759,8 @@ static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
     L.xa = off; off += align256((size_t)rows * m->hidden * 2);
     L.xb = off; off += align256((size_t)rows * m->hidden * 2);
     L.xn = off; off += align256((size_t)rows * m->hidden * 2);       // normalised rows of a prompt (prefill GEMMs)
+    L.parts_bytes = linear_rows_scratch_bytes(rows, m->hidden, m->inter);   // K parts of a prompt's down projection
+    L.parts = off; off += align256(L.parts_bytes);
     // prefill and decode attention share the partials region; the decode kernel's arrival counters follow it
     const size_t pre = qtts_attn_workspace_bytes(rows, m->n_heads, max_context);
     const size_t dec = attn2_partial_bytes(rows, m->n_heads, max_context);
@@ -1604,8 +1849,13 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
             if ((rc = qtts_rmsnorm(xa, H, L.post_norm, m->eps, xn, H, N, H, stream))) return rc;
             if ((rc = qtts_linear_swiglu(xn, H, L.wgu, nullptr, 0.f, act, m->inter, N, m->inter, H, stream))) return rc;
         } else if ((rc = qtts_linear_swiglu(xa, H, L.wgu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
-        if ((rc = qtts_linear_fused(act, m->inter, nullptr, 0, L.wdown, nullptr, xa, H, nullptr, 0.f, nullptr, 0, 0,
-                                    xb, H, N, H, m->inter, stream))) return rc;
+        {
+            LinArgs a;
+            a.x = act; a.ldx = m->inter; a.ids = nullptr; a.id_rows = 0; a.wp = (const uint4 *)L.wdown; a.bias = nullptr;
+            a.res = xa; a.ldr = H; a.nw = nullptr; a.eps = 0.f; a.xnorm_out = nullptr; a.ldxn = 0; a.out = xb; a.ldo = H;
+            a.M = N; a.N = H; a.K = m->inter; a.tiles_per_wg = 1;
+            if ((rc = launch_linear2(a, 0, (hipStream_t)stream, false, (float *)(m->ws + W.parts), W.parts_bytes))) return rc;
+        }
         // Fixed roles: xa = post-attention residual stream, xb = layer output.  The next layer reads xb
         // (qkv GEMM, o_proj residual) before its down_proj overwrites it, all stream-ordered.
         cur = xb;

@@ -34,6 +34,8 @@ _SIGS = {
     "qtts_attention_decode_fused": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _f, _p, _i, _i,
                                          _i, _i, _p, _p]),
     "qtts_model_forward_logits": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
+    "qtts_linear_workspace_bytes": (_sz, [_i, _i, _i]),
+    "qtts_linear_ws": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "qtts_linear_swiglu": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _p]),
     "qtts_rmsnorm": (_i, [_p, _i, _p, _f, _p, _i, _i, _i, _p]),
     "qtts_qknorm_rope_store": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
@@ -121,6 +123,19 @@ def linear(x, w_packed, N, bias=None, residual=None, norm_w=None, eps=1e-6, out=
     check(lib.qtts_linear(ptr(x), x.stride(0), ptr(w_packed), ptr(bias), ptr(residual),
                           residual.stride(0) if residual is not None else 0, ptr(norm_w), eps,
                           ptr(out), out.stride(0), M, N, K, stream()), "linear")
+    return out
+
+
+def linear_ws(x, w_packed, N, bias=None, residual=None, out=None):
+    """qtts_linear_ws with a workspace of the size the library asks for."""
+    M, K = x.shape
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    nbytes = int(lib.qtts_linear_workspace_bytes(M, N, K))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    check(lib.qtts_linear_ws(ptr(x), x.stride(0), ptr(w_packed), ptr(bias), ptr(residual),
+                             residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), M, N, K,
+                             ptr(ws), nbytes, stream()), "linear_ws")
     return out
 
 

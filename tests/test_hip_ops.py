@@ -353,7 +353,10 @@ def test_attention_decode_fused(hip, Hq, Hkv, ctxs):
 @pytest.mark.parametrize("M,N,K,kind", [(17, 256, 128, "norm"), (40, 4096, 2048, "norm"), (200, 2048, 2048, "res"),
                                         (200, 2048, 6144, "res"), (130, 1024, 3072, "bias"), (200, 6144, 1024, "swiglu"),
                                         (33, 3072, 2048, "head"), (200, 6144, 1024, "swiglu_plain"), (40, 12288, 2048, "swiglu_plain"),
-                                        (250, 4096, 2048, "plain"), (300, 512, 256, "plain"), (24, 256, 128, "res")])
+                                        (250, 4096, 2048, "plain"), (300, 512, 256, "plain"), (24, 256, 128, "res"),
+                                        (20, 2048, 2048, "plain"), (32, 6144, 1024, "swiglu_plain"), (64, 1024, 1024, "res"),
+                                        (200, 2048, 6144, "ws_res"), (35, 2048, 6144, "ws_bias"), (100, 1024, 3072, "ws_res"),
+                                        (1000, 2048, 2048, "res")])
 def test_linear_prefill_row_counts(hip, M, N, K, kind):
     """Prefill-sized row counts (several 16-row tiles, ragged last tile) through every GEMM variant of the
     decoder stack, against the oracle."""
@@ -382,6 +385,10 @@ def test_linear_prefill_row_counts(hip, M, N, K, kind):
             return torch.cat([out, xn], 1), w
         if kind == "res":
             return hip.linear(xd, wp, N, residual=res), w
+        if kind == "ws_res":
+            return hip.linear_ws(xd, wp, N, residual=res), w
+        if kind == "ws_bias":
+            return hip.linear_ws(xd, wp, N, bias=bias, residual=res), w
         return hip.linear(xd, wp, N, bias=bias, residual=res), w
 
     got, w = run()
@@ -400,8 +407,8 @@ def test_linear_prefill_row_counts(hip, M, N, K, kind):
     elif kind == "head":
         want = torch.cat([torch.nn.functional.linear(xf, w), xf], 1)
     else:
-        want = torch.nn.functional.linear(xf, w, bias.cpu() if kind == "bias" else None)
-        if kind in ("res", "bias"):
+        want = torch.nn.functional.linear(xf, w, bias.cpu() if kind in ("bias", "ws_bias") else None)
+        if kind in ("res", "bias", "ws_res", "ws_bias"):
             # the rounding that may differ by one ulp happens before the residual add, at the GEMM output's
             # magnitude: compare there (the add itself is exact to its own rounding in both)
             lin = want.float()

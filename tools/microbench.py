@@ -287,5 +287,34 @@ def frame():
         print(f"{name:18s} {us:8.1f} us per graph launch", flush=True)
 
 
+def prefill():
+    """Wall time of a talker prefill (prompt of QTTS_FRAME_PROMPT tokens) through FrameEngine.add_stream."""
+    import json, tempfile
+    sys.path.insert(0, ROOT)
+    import bench
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    from nano_qwen3tts_vllm.sampling_params import SamplingParams
+    from nano_qwen3tts_vllm.utils import synthetic
+    cfg = synthetic.make_config("1.7B")
+    tw, pw = bench.make_weights(cfg, dev)
+    d = tempfile.mkdtemp()
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+    fe = FrameEngine(d, max_streams=2, max_text_frames=16, talker_weights=tw, predictor_weights=pw,
+                     num_kvcache_blocks=8, max_num_batched_tokens=4096, codec_eos=None)
+    sp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
+    for plen in [int(v) for v in os.environ.get("QTTS_FRAME_PROMPT", "200").split(",")]:
+        ts = []
+        for i in range(6):
+            x = torch.randn(plen, 2048, device=dev) * 0.5
+            t = torch.randn(8, 2048, device=dev) * 0.1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sid = fe.add_stream(x, t, 8, sp, SamplingParams(temperature=0.9, max_tokens=17, do_sample=False))
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            fe.remove_stream(sid)
+        print(f"prefill {plen:4d} tokens: " + " ".join(f"{v:.2f}" for v in ts) + " ms", flush=True)
+
+
 if __name__ == "__main__":
-    {"launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
+    {"prefill": prefill, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
