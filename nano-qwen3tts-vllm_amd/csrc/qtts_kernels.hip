@@ -402,11 +402,14 @@ struct RowsArgs {
     bf16_t *out; int ldo;
     float *part; int mpad;       // EPI 2: part[kpart][mpad][N]
     int rgroups, KS;             // row groups of TM tiles; k-steps of a whole packed weight tile
+    long long *trace;            // tuning experiments only (null in production): 32 timestamps per workgroup
 };
 
 template <int KSW, int TM, int EPI>
 __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const uint4 *wp, int ldx, int N, int M,
                                                           int tiles_per_wg, const RowsArgs p) {
+#define QTTS_RTRACE(slot) do { if (p.trace && threadIdx.x == 0 && (slot) < 32) p.trace[(size_t)blockIdx.x * 32 + (slot)] = wall_clock64(); } while (0)
+    QTTS_RTRACE(0);
     extern __shared__ float4_t smem4[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -424,44 +427,49 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
 
     // rows beyond M read row 0: their accumulator columns are never stored
     Frag xb[TM][KSW];
-    int mrow[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        mrow[i] = (by * TM + i) * 16 + r;
-        const bf16_t *xp = x + (size_t)(mrow[i] < M ? mrow[i] : 0) * ldx + 32 * ks0 + 8 * g;
+        const int mi = (by * TM + i) * 16 + r;
+        const bf16_t *xp = x + (size_t)(mi < M ? mi : 0) * ldx + 32 * ks0 + 8 * g;
 #pragma unroll
         for (int k = 0; k < KSW; ++k) xb[i][k].u = *reinterpret_cast<const uint4 *>(xp + 32 * k);
     }
+    // Two weight tiles are in flight: a fragment register is refilled with the tile after next as soon as its
+    // multiplications are issued, so the loads of tile t+2 go out while tile t is still being multiplied.
+    const int nt = t_end - t_begin;
     Frag a[2][KSW];
-    {
-        const uint4 *wptr = wp + ((size_t)t_begin * p.KS + ks0) * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < KSW; ++k) a[0][k].u = wptr[k * 64];
+    for (int j = 0; j < 2; ++j) {
+        const uint4 *wptr = wp + ((size_t)min(t_begin + j, t_end - 1) * p.KS + ks0) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < KSW; ++k) a[j][k].u = wptr[k * 64];
     }
-    auto tile_body = [&](const int cur, const int t, const int it) {
-        uint2 resw = make_uint2(0, 0), biasw = make_uint2(0, 0);
+    auto tile_body = [&](const int cur, const int it) {
+        const int t = t_begin + it;
+        uint2 resw = make_uint2(0, 0);
         if (EPI == 0 && wave < TM) {
             const int m = (by * TM + wave) * 16 + r;
             if (p.res && m < M) resw = *reinterpret_cast<const uint2 *>(p.res + (size_t)m * p.ldr + 16 * t + 4 * g);
-            if (p.bias) biasw = *reinterpret_cast<const uint2 *>(p.bias + 16 * t + 4 * g);
         }
-        if (t + 1 < t_end) {
-            const uint4 *wptr = wp + ((size_t)(t + 1) * p.KS + ks0) * 64 + lane;
-#pragma unroll
-            for (int k = 0; k < KSW; ++k) a[cur ^ 1][k].u = wptr[k * 64];
-        }
+        // unconditional (the last tiles are requested again at the end): with straight-line code the compiler's
+        // wait counts let exactly the younger tile's loads stay in flight
+        const uint4 *wnext = wp + ((size_t)min(t + 2, t_end - 1) * p.KS + ks0) * 64 + lane;
         float4_t acc[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < KSW; ++k)
+        for (int k = 0; k < KSW; ++k) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][k].v, xb[i][k].v, acc[i], 0, 0, 0);
+            a[cur][k].u = wnext[k * 64];
+        }
         float4_t *red = smem4 + (size_t)(it & 1) * NW * TM * 64;
 #pragma unroll
         for (int i = 0; i < TM; ++i) red[(wave * TM + i) * 64 + lane] = acc[i];
+        QTTS_RTRACE(1 + 2 * it);
         __syncthreads();
+        QTTS_RTRACE(2 + 2 * it);
         if (wave >= TM) return;
         // wave i finishes row tile i of this weight tile
         const float4_t *mine = red + wave * 64;
@@ -493,6 +501,8 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
         }
         if (m < M) {
             float v[4], rf[4], bfv[4];
+            uint2 biasw = make_uint2(0, 0);
+            if (p.bias) biasw = *reinterpret_cast<const uint2 *>(p.bias + 16 * t + 4 * g);
             unpack2(resw.x, rf[0], rf[1]);
             unpack2(resw.y, rf[2], rf[3]);
             unpack2(biasw.x, bfv[0], bfv[1]);
@@ -509,11 +519,20 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
                 make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
         }
     };
+    // groups of four tiles as straight-line code: inside a group the compiler counts outstanding loads exactly
+    // and the younger tile stays in flight; at a loop head it waits for everything
     int it = 0;
-    for (int t = t_begin; t < t_end; t += 2, it += 2) {
-        tile_body(0, t, it);
-        if (t + 1 < t_end) tile_body(1, t + 1, it + 1);
+    for (; it + 4 <= nt; it += 4) {
+        tile_body(0, it);
+        tile_body(1, it + 1);
+        tile_body(0, it + 2);
+        tile_body(1, it + 3);
     }
+    if (it < nt) tile_body(0, it);
+    if (it + 1 < nt) tile_body(1, it + 1);
+    if (it + 2 < nt) tile_body(0, it + 2);
+    QTTS_RTRACE(31);
+#undef QTTS_RTRACE
 }
 
 // Sum of the K parts + the bias/residual epilogue (same rounding points as the single-launch epilogue).
@@ -599,9 +618,12 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     RowsArgs r;
     r.bias = a.bias; r.res = a.res; r.ldr = a.ldr; r.out = a.out; r.ldo = a.ldo;
     r.part = scratch; r.mpad = a.M; r.rgroups = (mtiles + TM - 1) / TM; r.KS = KS;
+    r.trace = g_trace;
     const int ntiles = a.N / 16;
-    // one round of workgroups (a CU holds one): as many as fit in 256, each streaming `tpw` weight tiles
-    const int gx_max = std::max(1, 256 / (r.rgroups * kparts));
+    // One round of workgroups (a CU holds one, an XCD 32): workgroup i runs on XCD i % 8 and the launch is laid out
+    // in groups of 8 column blocks x all row groups (x K parts), so the groups of 8 that fit one round are
+    // 32 / (row groups x K parts); each workgroup streams `tpw` weight tiles.
+    const int gx_max = 8 * std::max(1, 32 / (r.rgroups * kparts));
     const int tpw = (ntiles + gx_max - 1) / gx_max;
     const int gx = (ntiles + tpw - 1) / tpw;
     dim3 grid(((gx + 7) / 8) * 8 * r.rgroups, kparts);

@@ -287,6 +287,79 @@ def frame():
         print(f"{name:18s} {us:8.1f} us per graph launch", flush=True)
 
 
+def rows():
+    """Prompt GEMMs at the talker's shapes: rows x (cold weights: 28 different matrices in turn | one hot matrix)."""
+    H, I = 2048, 6144
+    nl = 28
+    hip.lib.qtts_debug_linear(int(os.environ.get("QTTS_LINEAR_DBG", "0")))
+    shapes = [("qkv", 4096, H, "plain"), ("o_proj", H, H, "res"), ("gate_up", 2 * I, H, "swiglu"), ("down", H, I, "ws")]
+    only = os.environ.get("QTTS_ROWS_ONLY")
+    for name, N, K, kind in shapes:
+        if only and name != only:
+            continue
+        ws_w = [(torch.randn(N * K // 4, device=dev) * 0.02).bfloat16().repeat(4) for _ in range(nl)]
+        for M in [int(v) for v in os.environ.get("QTTS_ROWS", "32,64,128,200,400").split(",")]:
+            x = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
+            res = torch.randn(M, N, device=dev).bfloat16()
+            out = torch.empty(M, N // 2 if kind == "swiglu" else N, dtype=torch.bfloat16, device=dev)
+
+            def call(w):
+                if kind == "swiglu":
+                    hip.linear_swiglu(x, w, N // 2, out=out)
+                elif kind == "ws":
+                    hip.linear_ws(x, w, N, residual=res, out=out)
+                elif kind == "res":
+                    hip.linear(x, w, N, residual=res, out=out)
+                else:
+                    hip.linear(x, w, N, out=out)
+            cold = timed(lambda: [call(w) for w in ws_w], nl)
+            hot = timed(lambda: [call(ws_w[0]) for _ in range(nl)], nl)
+            fl = 2.0 * M * N * K
+            print(f"{name:8s} M={M:4d}: cold {cold:7.2f} us ({fl / cold / 1e6:6.1f} TFLOP/s, weights at {N * K * 2 / cold / 1e6:5.2f} TB/s)"
+                  f"   hot {hot:7.2f} us", flush=True)
+
+
+def rowtrace():
+    """Timestamps inside one prompt GEMM launch (gate/up shape): per workgroup, when the multiplications of tile i
+    were issued and when its reduction barrier opened (100 MHz device clock)."""
+    import numpy as np
+    H, I = 2048, 6144
+    M = int(os.environ.get("QTTS_ROWS", "200"))
+    which = os.environ.get("QTTS_ROWS_ONLY", "gate_up")
+    N, K = {"gate_up": (2 * I, H), "down": (H, I), "qkv": (4096, H), "o_proj": (H, H)}[which]
+    ws = [(torch.randn(N * K // 4, device=dev) * 0.02).bfloat16().repeat(4) for _ in range(4)]
+    x = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
+    out = torch.empty(M, I if which == "gate_up" else N, dtype=torch.bfloat16, device=dev)
+    buf = torch.zeros(1024 * 32, dtype=torch.int64, device=dev)
+
+    def call(w):
+        if which == "gate_up":
+            hip.linear_swiglu(x, w, I, out=out)
+        elif which == "down":
+            hip.linear_ws(x, w, N, out=out)
+        else:
+            hip.linear(x, w, N, out=out)
+    for w in ws:
+        call(w)
+    torch.cuda.synchronize()
+    hip.lib.qtts_debug_linear_trace(hip.ptr(buf))
+    call(ws[0])
+    hip.lib.qtts_debug_linear_trace(None)
+    torch.cuda.synchronize()
+    t = buf.cpu().numpy().reshape(1024, 32).astype(np.float64) * 10.0
+    act = t[:, 1] > 0
+    t = t[act]
+    t0 = t[:, 0].min()
+    print(f"{which} M={M}: {int(act.sum())} active workgroups; start spread {t[:, 0].max() - t0:.0f} ns; last end {t[:, 31].max() - t0:.0f} ns")
+    for it in range(15):
+        a, b = t[:, 1 + 2 * it], t[:, 2 + 2 * it]
+        ok = a > 0
+        if not ok.any():
+            break
+        print(f"  tile {it:2d}: mfma issued median {np.median(a[ok]) - t0:7.0f} max {a[ok].max() - t0:7.0f} | barrier open median "
+              f"{np.median(b[ok]) - t0:7.0f} max {b[ok].max() - t0:7.0f}  (n={int(ok.sum())})")
+
+
 def prefill():
     """Wall time of a talker prefill (prompt of QTTS_FRAME_PROMPT tokens) through FrameEngine.add_stream."""
     import json, tempfile
@@ -317,4 +390,4 @@ def prefill():
 
 
 if __name__ == "__main__":
-    {"prefill": prefill, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
+    {"prefill": prefill, "rows": rows, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
