@@ -48,6 +48,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }   // round through bf16
+// x * sigmoid(x) on the hardware exp2 and reciprocal (a few fp32 ulp, far inside the bf16 rounding that follows; the
+// library expf and IEEE division cost ten times the instructions on the serial path of a GEMM epilogue).
+// exp overflow gives 1/inf = 0, i.e. -0 for very negative x, as the exact quotient does.
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // Cross-lane sums inside a 16-lane row on the DPP path (no LDS crossbar round trip).
 template <int CTRL>
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
                 float g0, g1, u0, u1;
                 unpack2(gw[j], g0, g1);
                 unpack2(uw[j], u0, u1);
-                const float s0 = rbf(g0 / (1.0f + expf(-g0))), s1 = rbf(g1 / (1.0f + expf(-g1)));
+                const float s0 = rbf(silu_f(g0)), s1 = rbf(silu_f(g1));
                 ow[j] = pack2(s0 * u0, s1 * u1);
             }
             xb[i].u = make_uint4(ow[0], ow[1], ow[2], ow[3]);
@@ -255,8 +259,14 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             xb[i].u = *reinterpret_cast<const uint4 *>(xp + 32 * i);
         }
     }
-    // The (small) activation loads above go out first: vector memory requests of a wave are served in order, so
-    // behind KSW KiB of weight requests they would arrive last although everything else waits for them.
+    // The (small) activation loads above and the norm weights go out first: vector memory requests of a wave are
+    // served in order, so behind KSW KiB of weight requests they would arrive last although everything else
+    // waits for them.
+    uint4 nwv[PRO == 1 ? KSW : 1];
+    if (PRO == 1) {
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) nwv[i] = *reinterpret_cast<const uint4 *>(p.nw + 32 * (ks0 + i) + 8 * g);
+    }
     Frag a[DB ? 2 : 1][KSW];
     {
         const uint4 *wptr = p.wp + ((size_t)((p.dbg & 1) ? 0 : t_begin) * KS + ks0) * 64 + lane;
@@ -265,13 +275,21 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             if (arow) a[0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
             else a[0][i].u = make_uint4(0, 0, 0, 0);
         }
+        if (DB) {
+            // tile loop: two tiles are in flight from the start; a fragment register is refilled with the tile
+            // after next as soon as its multiplication is issued (the last tile is requested again at the end,
+            // which keeps the code free of branches so that the compiler's wait counts stay exact)
+            const bool two = t_begin + 1 < t_end;
+            const uint4 *wptr1 = p.wp + ((size_t)((p.dbg & 1) || !two ? 0 : t_begin + 1) * KS + (two ? ks0 : 0)) * 64 + lane;
+            const int wstep1 = two ? 64 : 0;
+#pragma unroll
+            for (int i = 0; i < KSW; ++i)
+                a[DB ? 1 : 0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr1 + i * wstep1));
+        }
     }
 
     float *normred = reinterpret_cast<float *>(smem4 + (size_t)2 * NW * 64);
     if (PRO == 1) {
-        uint4 nwv[KSW];                                  // requested before the barrier so both L2 trips overlap
-#pragma unroll
-        for (int i = 0; i < KSW; ++i) nwv[i] = *reinterpret_cast<const uint4 *>(p.nw + 32 * (ks0 + i) + 8 * g);
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < KSW; ++i) {
@@ -319,16 +337,17 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             if (p.res && mvalid) resw = *reinterpret_cast<const uint2 *>(p.res + (size_t)m * p.ldr + 16 * t + 4 * g);
             if (p.bias) biasw = *reinterpret_cast<const uint2 *>(p.bias + 16 * t + 4 * g);
         }
-        if (DB && t + 1 < t_end) {
-            const uint4 *wptr = p.wp + ((size_t)((p.dbg & 1) ? 0 : (t + 1)) * KS + ks0) * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < KSW; ++i)
-                a[DB ? (cur ^ 1) : 0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
-        }
+        // past the last tile the refills still execute (no branch) but all read one 1 KiB fragment that is in
+        // the cache already
+        const bool more = t + 2 < t_end;
+        const uint4 *wnext = p.wp + ((size_t)((p.dbg & 1) || !more ? 0 : t + 2) * KS + (more ? ks0 : 0)) * 64 + lane;
+        const int wstep = more ? 64 : 0;
         float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < KSW; ++i)
+        for (int i = 0; i < KSW; ++i) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[DB ? cur : 0][i].v, xb[i].v, acc, 0, 0, 0);
+            if (DB) a[DB ? cur : 0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wnext + i * wstep));
+        }
         float4_t *red = smem4 + (size_t)(it & 1) * NW * 64;
         red[wave * 64 + lane] = acc;
         QTTS_TRACE(1);
@@ -346,7 +365,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float gv = rbf(sum[j]);
-                            const float sv = rbf(gv / (1.0f + expf(-gv)));
+                            const float sv = rbf(silu_f(gv));
                             v[j] = sv * rbf(ups[j]);
                         }
                         *reinterpret_cast<uint2 *>(p.out + (size_t)m * p.ldo + 8 * t + 4 * g) =
@@ -383,11 +402,17 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         QTTS_TRACE(3);
         return;
     }
-    int it = 0;
-    for (int t = t_begin; t < t_end; t += 2, it += 2) {
-        tile_body(0, t, it);
-        if (t + 1 < t_end) tile_body(1, t + 1, it + 1);
+    int t = t_begin;
+    for (; t + 4 <= t_end; t += 4) {
+        tile_body(0, t, 0);
+        tile_body(1, t + 1, 1);
+        tile_body(0, t + 2, 0);
+        tile_body(1, t + 3, 1);
     }
+    if (t < t_end) tile_body(0, t, 0);
+    if (t + 1 < t_end) tile_body(1, t + 1, 1);
+    if (t + 2 < t_end) tile_body(0, t + 2, 0);
+    QTTS_TRACE(3);
 }
 
 // ------------------------------------------------------------------ linear over several row tiles (prompts)
@@ -440,9 +465,11 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
     Frag a[2][KSW];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const uint4 *wptr = wp + ((size_t)min(t_begin + j, t_end - 1) * p.KS + ks0) * 64 + lane;
+        const bool have = j < nt;
+        const uint4 *wptr = wp + ((size_t)(have ? t_begin + j : 0) * p.KS + (have ? ks0 : 0)) * 64 + lane;
+        const int wstep0 = have ? 64 : 0;
 #pragma unroll
-        for (int k = 0; k < KSW; ++k) a[j][k].u = wptr[k * 64];
+        for (int k = 0; k < KSW; ++k) a[j][k].u = wptr[k * wstep0];
     }
     auto tile_body = [&](const int cur, const int it) {
         const int t = t_begin + it;
@@ -451,9 +478,11 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
             const int m = (by * TM + wave) * 16 + r;
             if (p.res && m < M) resw = *reinterpret_cast<const uint2 *>(p.res + (size_t)m * p.ldr + 16 * t + 4 * g);
         }
-        // unconditional (the last tiles are requested again at the end): with straight-line code the compiler's
-        // wait counts let exactly the younger tile's loads stay in flight
-        const uint4 *wnext = wp + ((size_t)min(t + 2, t_end - 1) * p.KS + ks0) * 64 + lane;
+        // unconditional: with straight-line code the compiler's wait counts let exactly the younger tile's loads
+        // stay in flight; past the last tile the refills all read one 1 KiB fragment that is cached already
+        const bool more = it + 2 < nt;
+        const uint4 *wnext = wp + ((size_t)(more ? t + 2 : 0) * p.KS + (more ? ks0 : 0)) * 64 + lane;
+        const int wstep = more ? 64 : 0;
         float4_t acc[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -462,7 +491,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][k].v, xb[i][k].v, acc[i], 0, 0, 0);
-            a[cur][k].u = wnext[k * 64];
+            a[cur][k].u = wnext[k * wstep];
         }
         float4_t *red = smem4 + (size_t)(it & 1) * NW * TM * 64;
 #pragma unroll
@@ -490,7 +519,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float gv = rbf(sum[j]);
-                        const float sv = rbf(gv / (1.0f + expf(-gv)));
+                        const float sv = rbf(silu_f(gv));
                         v[j] = sv * rbf(ups[j]);
                     }
                     *reinterpret_cast<uint2 *>(p.out + (size_t)m * p.ldo + 8 * t + 4 * g) =

@@ -177,7 +177,7 @@ def trace():
     import numpy as np
     B, NL = 8, 40
     for name, N, K, kind in (("o pred", 1024, 2048, "res"), ("qkv pred", 4096, 1024, "norm"), ("down pred", 1024, 3072, "res"),
-                             ("o 1.7B", 2048, 2048, "res")):
+                             ("o 1.7B", 2048, 2048, "res"), ("gate/up 1.7B", 12288, 2048, "swiglu"), ("down 1.7B", 2048, 6144, "res")):
         ws = [torch.randn(N * K, device=dev).bfloat16() * 0.02 for _ in range(NL)]
         x = torch.randn(B, K, device=dev).bfloat16()
         nw = torch.ones(K, device=dev).bfloat16()
@@ -187,7 +187,10 @@ def trace():
 
         def run():
             for w in ws:
-                hip.linear_fused(x, w, N, K=K, norm_w=nw if kind == "norm" else None, residual=res if kind != "norm" else None, out=out)
+                if kind == "swiglu":
+                    hip.linear_swiglu(x, w, N // 2, norm_w=nw, out=out)
+                else:
+                    hip.linear_fused(x, w, N, K=K, norm_w=nw if kind == "norm" else None, residual=res if kind != "norm" else None, out=out)
         st = torch.cuda.Stream()
         with torch.cuda.stream(st):
             run()
@@ -240,6 +243,15 @@ def dominant():
                 hip.linear_swiglu(x, w, I, norm_w=nw, out=out)
         st.synchronize()
     print("launches", 280, "algorithmic bytes per launch", 2 * I * H * 2 + B * H * 2 + B * I * 2, flush=True)
+    if os.environ.get("QTTS_DOMINANT_TIMED"):
+        def run():
+            for w in ws:
+                hip.linear_swiglu(x, w, I, norm_w=nw, out=out)
+        eager = timed(run, len(ws))
+        with torch.cuda.stream(st):
+            g = hip.Graph.capture(run)
+        graph = timed(lambda: g.launch(), len(ws))
+        print(f"per launch: eager {eager:.2f} us, inside one graph {graph:.2f} us", flush=True)
 
 
 def frame():
@@ -346,6 +358,14 @@ def rowtrace():
     call(ws[0])
     hip.lib.qtts_debug_linear_trace(None)
     torch.cuda.synchronize()
+    if M <= 16:
+        t = buf.cpu().numpy()[:4096].reshape(1024, 4).astype(np.float64) * 10.0
+        t = t[t[:, 0] > 0]
+        t0 = t[:, 0].min()
+        print(f"{which} M={M}: {len(t)} workgroups; start spread {t[:, 0].max() - t0:.0f} ns; last tile multiplied median "
+              f"{np.median(t[:, 1]) - t0:.0f} max {t[:, 1].max() - t0:.0f}; its barrier open max {t[:, 2].max() - t0:.0f}; end max {t[:, 3].max() - t0:.0f} "
+              f"median {np.median(t[:, 3]) - t0:.0f} min {t[:, 3].min() - t0:.0f}")
+        return
     t = buf.cpu().numpy().reshape(1024, 32).astype(np.float64) * 10.0
     act = t[:, 1] > 0
     t = t[act]
