@@ -34,6 +34,18 @@ if os.environ.get("QTTS_PROBE_SIZES"):
         t = per_launch(lambda w: hip.linear(x, w, N, out=out), ws)
         print(f"N={N:6d}: {N * 4096 / 1e6:6.1f} MB  {t:7.2f} us per launch  {N * 4096 / t / 1e6:5.2f} TB/s", flush=True)
         del ws
+elif os.environ.get("QTTS_PROBE_PRED"):
+    # the predictor's gate/up launch (K=1024, N=6144: 384 tiles) with 1, 2 or 3 tiles per workgroup
+    N, K = 6144, 1024
+    xk = torch.randn(8, K, device=dev).bfloat16()
+    nk = torch.ones(K, device=dev).bfloat16()
+    ws = [(torch.randn(N * K // 8, device=dev) * 0.02).bfloat16().repeat(8) for _ in range(60)]
+    out = torch.empty(8, N // 2, dtype=torch.bfloat16, device=dev)
+    for t in (0, 4, 3, 2):
+        hip.lib.qtts_tune_linear(0, t)
+        tm = per_launch(lambda w: hip.linear_swiglu(xk, w, N // 2, norm_w=nk, out=out), ws)
+        print(f"target {t * 64 or 'auto':>4} workgroups: {tm:6.2f} us per launch", flush=True)
+    hip.lib.qtts_tune_linear(0, 0)
 else:
     N = 12288
     ws = [(torch.randn(N * 2048 // 8, device=dev) * 0.02).bfloat16().repeat(8) for _ in range(40)]
