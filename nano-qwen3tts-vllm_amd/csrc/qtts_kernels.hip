@@ -1070,6 +1070,188 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float *__restri
     out[(size_t)row * ldo + (size_t)hq * 128 + d] = f2bf(o / L);
 }
 
+// ------------------------------------------------------------------ prompt attention on MFMA
+// Rows of a prompt, 16 at a time: grid (row tiles, Hkv), 8*G waves per workgroup; wave (tg, h) owns query head
+// kvh*G + h of the tile's 16 rows and every eighth 32-token step of the context (a step is a chain of dependent
+// round trips, so the steps of a context run side by side rather than one after the other), the token groups merge
+// through LDS at the end (no partials in global memory, no combine launch).
+//   S^T[token][row] = K Q^T   A = 16 cached K rows (one 16-byte fragment per lane straight from the cache),
+//                             B = the 16 query rows; lane (g, r) ends up with row r's scores of tokens 4g..4g+3:
+//                             a query row lives in 4 lanes, its softmax statistics need two cross-lane steps.
+//   O^T[dim][row]  = V^T P^T  B = the lane's own 8 probabilities of the two 16-token tiles (bf16), A = V^T, read
+//                             out of the wave's private LDS copy of the 32 V rows, two bytes at a time (the
+//                             contraction runs over tokens, the cache holds a token's 128 dims contiguously).
+// The rescale factor of the running maximum belongs to the lane's own row in both layouts.
+// Rows of one tile may belong to different sequences (packed prompts): the sequences present in the tile are
+// walked one after the other with the other rows masked.  Causality is context_lens[row] = position + 1.
+#define PA_VROW 272           // bytes of one V row in LDS: 4 rows apart = 16 banks, conflict-free transposed reads
+#define PA_WAVE_LDS (32 * PA_VROW)
+#define PA_NTG 8              // token groups (waves per query head) of a workgroup
+template <int G>
+__global__ __launch_bounds__(64 * PA_NTG * G) void prefill_attn_mfma_kernel(
+    const bf16_t *__restrict__ q, int ldq, const bf16_t *__restrict__ kc, const bf16_t *__restrict__ vc,
+    const int32_t *__restrict__ block_tables, int max_blocks, const int32_t *__restrict__ row_seq,
+    const int32_t *__restrict__ context_lens, float scale, bf16_t *__restrict__ out, int ldo, int N, int Hkv) {
+    constexpr int NTG = PA_NTG;
+    constexpr float NEG = -1e30f;
+    extern __shared__ unsigned char pa_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int tg = wave / G, h = wave % G;
+    const int kvh = blockIdx.y, hq = kvh * G + h;
+    const int m = blockIdx.x * 16 + r;
+    const bool rvalid = m < N;
+    const int mc = rvalid ? m : N - 1;
+    const int ctx = rvalid ? context_lens[mc] : 0;
+    const int seq = row_seq ? row_seq[mc] : mc;
+    unsigned char *vs = pa_smem + (size_t)wave * PA_WAVE_LDS;
+
+    Frag qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks].u = *reinterpret_cast<const uint4 *>(q + (size_t)mc * ldq + (size_t)hq * 128 + 32 * ks + 8 * g);
+
+    float mrun = NEG, lrun = 0.f;
+    float4_t o[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    bool done = !(rvalid && ctx > 0);
+    for (int pass = 0; pass < 16; ++pass) {
+        const unsigned long long pend = __ballot(!done) & 0xffffull;       // lanes 0..15 carry the 16 rows
+        if (pend == 0) break;
+        const int lead = __ffsll((long long)pend) - 1;
+        const int cur = __shfl(seq, lead);
+        const bool act = !done && seq == cur;
+        done = done || act;
+        int cmax = act ? ctx : 0;
+        cmax = max(cmax, __shfl_xor(cmax, 1));
+        cmax = max(cmax, __shfl_xor(cmax, 2));
+        cmax = max(cmax, __shfl_xor(cmax, 4));
+        cmax = max(cmax, __shfl_xor(cmax, 8));
+        const int32_t *bt = block_tables + (size_t)cur * max_blocks;
+        const int nsteps = (cmax + 31) >> 5;
+        const int climit = act ? ctx : 0;                                  // tokens this lane's row may see
+        for (int step = tg; step < nsteps; step += NTG) {
+            const int t0 = step * 32;
+            // K fragments of the two 16-token tiles (tokens past the longest row re-read its last token: masked)
+            Frag ka[4], kb[4];
+            {
+                const int ta = min(t0 + r, cmax - 1), tb = min(t0 + 16 + r, cmax - 1);
+                const bf16_t *pa = kc + (((size_t)bt[min(ta >> 8, max_blocks - 1)] * QTTS_KV_BLOCK + (ta & 255)) * Hkv + kvh) * 128 + 8 * g;
+                const bf16_t *pb = kc + (((size_t)bt[min(tb >> 8, max_blocks - 1)] * QTTS_KV_BLOCK + (tb & 255)) * Hkv + kvh) * 128 + 8 * g;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    ka[ks].u = *reinterpret_cast<const uint4 *>(pa + 32 * ks);
+                    kb[ks].u = *reinterpret_cast<const uint4 *>(pb + 32 * ks);
+                }
+            }
+            // the 32 V rows into this wave's LDS region, as they lie in the cache
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int tl = 4 * i + g;
+                const int tv = min(t0 + tl, cmax - 1);
+                const uint4 v = *reinterpret_cast<const uint4 *>(
+                    vc + (((size_t)bt[min(tv >> 8, max_blocks - 1)] * QTTS_KV_BLOCK + (tv & 255)) * Hkv + kvh) * 128 + 8 * r);
+                *reinterpret_cast<uint4 *>(vs + tl * PA_VROW + 16 * r) = v;
+            }
+            // the rows are read back two bytes at a time by other lanes of this wave: LDS serves a wave's requests in
+            // order, the compiler must not move the differently-typed reads across the writes either
+            asm volatile("" ::: "memory");
+            float4_t sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[ks].v, qf[ks].v, sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb[ks].v, qf[ks].v, sb, 0, 0, 0);
+            }
+            float sv[8];
+            float rmax = NEG;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sv[i] = (t0 + 4 * g + i) < climit ? sa[i] * scale : NEG;
+                sv[4 + i] = (t0 + 16 + 4 * g + i) < climit ? sb[i] * scale : NEG;
+                rmax = fmaxf(rmax, fmaxf(sv[i], sv[4 + i]));
+            }
+            rmax = fmaxf(rmax, __shfl_xor(rmax, 16));
+            rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
+            const float mnew = fmaxf(mrun, rmax);
+            const float alpha = __expf(mrun - mnew);                       // 1 while the row has seen nothing
+            mrun = mnew;
+            // a probability enters the second product as the sum of two bf16 numbers (16 mantissa bits), so that the
+            // result stays as close to the fp32 softmax of the definition as the per-row kernel's
+            float psum = 0.f;
+            Frag pf, pl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float pr = sv[i] > 0.5f * NEG ? __expf(sv[i] - mnew) : 0.f;
+                pf.h[i] = f2bf(pr);
+                pl.h[i] = f2bf(pr - bf2f(pf.h[i]));
+                psum += pr;
+            }
+            lrun = lrun * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                o[dt] *= alpha;
+                Frag vt;
+                const unsigned char *col = vs + 2 * (16 * dt + r);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vt.h[i] = *reinterpret_cast<const bf16_t *>(col + (4 * g + i) * PA_VROW);
+                    vt.h[4 + i] = *reinterpret_cast<const bf16_t *>(col + (16 + 4 * g + i) * PA_VROW);
+                }
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt.v, pf.v, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt.v, pl.v, o[dt], 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+    // ---- merge the token groups of a head: (m, l, O^T) through the wave's LDS region
+    lrun += __shfl_xor(lrun, 16);
+    lrun += __shfl_xor(lrun, 32);
+    __syncthreads();                                                       // (waves may still be reading V rows)
+    {
+        float4_t *po = reinterpret_cast<float4_t *>(vs);                   // [8 d-tiles][64 lanes]
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) po[dt * 64 + lane] = o[dt];
+        float *pml = reinterpret_cast<float *>(vs + 8192);                 // [16 rows][2]
+        if (g == 0) {
+            pml[2 * r] = mrun;
+            pml[2 * r + 1] = lrun;
+        }
+    }
+    __syncthreads();
+    if (tg != 0) return;
+    float M = NEG;
+#pragma unroll
+    for (int k = 0; k < NTG; ++k) {
+        const float *pml = reinterpret_cast<const float *>(pa_smem + (size_t)(k * G + h) * PA_WAVE_LDS + 8192);
+        M = fmaxf(M, pml[2 * r]);
+    }
+    float L = 0.f, wk[NTG];
+#pragma unroll
+    for (int k = 0; k < NTG; ++k) {
+        const float *pml = reinterpret_cast<const float *>(pa_smem + (size_t)(k * G + h) * PA_WAVE_LDS + 8192);
+        wk[k] = __expf(pml[2 * r] - M);
+        L += pml[2 * r + 1] * wk[k];
+    }
+    const float inv = L > 0.f ? 1.0f / L : 0.f;                            // a row without context gives zeros
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+        float4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NTG; ++k) {
+            const float4_t *po = reinterpret_cast<const float4_t *>(pa_smem + (size_t)(k * G + h) * PA_WAVE_LDS);
+            acc += po[dt * 64 + lane] * wk[k];
+        }
+        if (rvalid)
+            *reinterpret_cast<uint2 *>(out + (size_t)m * ldo + (size_t)hq * 128 + 16 * dt + 4 * g) =
+                make_uint2(pack2(acc[0] * inv, acc[1] * inv), pack2(acc[2] * inv, acc[3] * inv));
+    }
+}
+
+static int g_mfma_attn_rows = 112;      // rows from which qtts_paged_attention takes the MFMA kernel for prompts
+extern "C" void qtts_tune_prompt_attention(int min_rows) { g_mfma_attn_rows = min_rows; }
+
 static inline int attn_nsplit(int max_context) { return max_context <= ATT_SPLIT ? 1 : (max_context + ATT_SPLIT - 1) / ATT_SPLIT; }
 
 extern "C" size_t qtts_attn_workspace_bytes(int N, int Hq, int max_context) {
@@ -1088,12 +1270,41 @@ extern "C" int qtts_paged_attention(const void *q, int ldq, const void *k_cache,
     QCHECK(max_blocks > 0 && max_context > 0 && max_context <= max_blocks * QTTS_KV_BLOCK,
            "paged_attention: max_context %d exceeds %d blocks", max_context, max_blocks);
     const int G = Hq / Hkv;
+    hipStream_t s = (hipStream_t)stream;
+    if (row_seq && N >= g_mfma_attn_rows && (G == 1 || G == 2)) {
+        // several rows per sequence (a prompt): 16 rows per workgroup on MFMA.  Below about a hundred rows the
+        // per-row kernel is faster (a 48-token prompt: 6.6 against 10 us per layer; 200 tokens: 25 against 14 us)
+        const dim3 grid((N + 15) / 16, Hkv);
+        const size_t shmem = (size_t)PA_NTG * G * PA_WAVE_LDS;
+        if (G == 1) {
+            static bool once1 = false;
+            if (!once1) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_attn_mfma_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                once1 = true;
+            }
+            hipLaunchKernelGGL((prefill_attn_mfma_kernel<1>), grid, dim3(64 * PA_NTG), shmem, s, (const bf16_t *)q, ldq,
+                               (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq,
+                               context_lens, scale, (bf16_t *)out, ldo, N, Hkv);
+        } else {
+            static bool once = false;
+            if (!once) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_attn_mfma_kernel<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                once = true;
+            }
+            hipLaunchKernelGGL((prefill_attn_mfma_kernel<2>), grid, dim3(128 * PA_NTG), shmem, s, (const bf16_t *)q, ldq,
+                               (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq,
+                               context_lens, scale, (bf16_t *)out, ldo, N, Hkv);
+        }
+        QLAUNCH();
+        return QTTS_OK;
+    }
     const int ns = attn_nsplit(max_context);
     QCHECK(ns == 1 || workspace, "paged_attention: workspace required for contexts > %d", ATT_SPLIT);
     float *part_o = (float *)workspace;
     float *part_ml = part_o ? part_o + (size_t)N * Hq * ns * 128 : nullptr;
     dim3 grid(N, Hkv, ns);
-    hipStream_t s = (hipStream_t)stream;
 #define QA(G_) case G_: hipLaunchKernelGGL((paged_attn_kernel<G_>), grid, dim3(256), 0, s, (const bf16_t *)q, ldq, \
         (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq, context_lens, scale, \
         (bf16_t *)out, ldo, Hkv, part_o, part_ml, ns); break;

@@ -69,6 +69,7 @@ _SIGS = {
     "qtts_graph_destroy": (None, [_p]),
     "qtts_tune_linear": (None, [_i, _i]),
     "qtts_tune_subtiles": (None, [_i]),
+    "qtts_tune_prompt_attention": (None, [_i]),
     "qtts_debug_linear": (None, [_i]),
     "qtts_debug_linear_trace": (None, [_p]),
     "qtts_debug_grid_barrier": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
@@ -78,7 +79,7 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-EXPORTED = [n for n in _SIGS if n not in ("qtts_tune_linear", "qtts_tune_subtiles", "qtts_debug_linear", "qtts_debug_linear_trace", "qtts_debug_grid_barrier")]
+EXPORTED = [n for n in _SIGS if n not in ("qtts_tune_linear", "qtts_tune_subtiles", "qtts_tune_prompt_attention", "qtts_debug_linear", "qtts_debug_linear_trace", "qtts_debug_grid_barrier")]
 
 
 class QttsError(RuntimeError):

@@ -186,31 +186,44 @@ def test_paged_attention_decode(hip, Hq, Hkv, ctxs):
             assert float(got[i].abs().sum()) == 0.0
 
 
-def test_paged_attention_prefill_rows(hip):
+@pytest.mark.parametrize("Hq,Hkv,lens", [(4, 2, [5, 140]), (16, 8, [200]), (2, 2, [33, 17, 300]), (4, 2, [16, 16, 7, 1, 1, 30, 2]),
+                                         (16, 8, [600]), (4, 2, [12]), (8, 4, [257, 31])])
+def test_paged_attention_prefill_rows(hip, Hq, Hkv, lens):
     """Causal prefill expressed as per-token rows over the just-stored cache equals
-    the packed varlen formulation (P/layers/attention.py:88-91)."""
-    g = torch.Generator().manual_seed(3)
-    Hq, Hkv = 4, 2
-    lens = [5, 140]
+    the packed varlen formulation (P/layers/attention.py:88-91): single and several prompts per launch, row tiles
+    that straddle prompts, contexts over several KV blocks, both head ratios of the MFMA kernel and (12 rows) the
+    per-row kernel."""
+    g = torch.Generator().manual_seed(3 + sum(lens))
     N = sum(lens)
     q = torch.randn(N, Hq, 128, generator=g).bfloat16()
     k = torch.randn(N, Hkv, 128, generator=g).bfloat16()
     v = torch.randn(N, Hkv, 128, generator=g).bfloat16()
-    cu = [0, 5, 145]
+    cu = [0]
+    for L in lens:
+        cu.append(cu[-1] + L)
     want = O.attention_prefill(q, k, v, cu, 128 ** -0.5)
-    kc = torch.zeros(3, 256, Hkv, 128, dtype=torch.bfloat16)
+    mb = (max(lens) + 255) // 256
+    nblk = mb * len(lens) + 1
+    kc = torch.zeros(nblk, 256, Hkv, 128, dtype=torch.bfloat16)
     vc = torch.zeros_like(kc)
-    bt = torch.tensor([[2], [0]], dtype=torch.int32)
+    bt = (torch.randperm(nblk - 1, generator=g) + 1)[:mb * len(lens)].reshape(len(lens), mb).to(torch.int32)
     slots, row_seq, ctx = [], [], []
     for s, L in enumerate(lens):
         for t in range(L):
-            slots.append(int(bt[s, 0]) * 256 + t)
+            slots.append(int(bt[s, t // 256]) * 256 + t % 256)
             row_seq.append(s)
             ctx.append(t + 1)
     O.store_kvcache(k, v, kc, vc, torch.tensor(slots))
-    got = hip.paged_attention(q.reshape(N, -1).to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV),
-                              torch.tensor(ctx, dtype=torch.int32, device=DEV), max(lens), 128 ** -0.5, Hq, Hkv,
-                              row_seq=torch.tensor(row_seq, dtype=torch.int32, device=DEV))
+    # both kernels at every size: the MFMA kernel from 17 rows, then the per-row kernel only
+    for min_rows in (17, 1 << 30):
+        hip.lib.qtts_tune_prompt_attention(min_rows)
+        try:
+            got = hip.paged_attention(q.reshape(N, -1).to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV),
+                                      torch.tensor(ctx, dtype=torch.int32, device=DEV), max(lens), 128 ** -0.5, Hq, Hkv,
+                                      row_seq=torch.tensor(row_seq, dtype=torch.int32, device=DEV))
+        finally:
+            hip.lib.qtts_tune_prompt_attention(112)
+        assert torch.allclose(got.float().cpu().view(N, Hq, 128), want.float(), atol=1e-2, rtol=2e-2), min_rows
     assert torch.allclose(got.float().cpu().view(N, Hq, 128), want.float(), atol=1e-2, rtol=2e-2)
 
 

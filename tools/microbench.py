@@ -395,6 +395,9 @@ def prefill():
     fe = FrameEngine(d, max_streams=2, max_text_frames=16, talker_weights=tw, predictor_weights=pw,
                      num_kvcache_blocks=8, max_num_batched_tokens=4096, codec_eos=None)
     sp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
+    hip.lib.qtts_debug_linear(int(os.environ.get("QTTS_LINEAR_DBG", "0")))
+    if os.environ.get("QTTS_MFMA_ATTN_ROWS"):
+        hip.lib.qtts_tune_prompt_attention(int(os.environ["QTTS_MFMA_ATTN_ROWS"]))
     for plen in [int(v) for v in os.environ.get("QTTS_FRAME_PROMPT", "200").split(",")]:
         ts = []
         for i in range(6):
