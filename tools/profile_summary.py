@@ -2,8 +2,8 @@
 
     python tools/profile_summary.py <dir with *_kernel_trace.csv and *_kernel_stats.csv> <out.txt> "<header line>"
 
-Besides the per-kernel totals it splits the dominant kernel's launches by grid (its decode launches carry 8 rows
-in one 16-row tile, its prefill launches carry up to 13 row tiles), because bench.py times the decode launch.
+Besides the per-kernel totals it lists the dominant kernel's launches by grid (the decode launch bench.py times)
+and the launches of the run's last frame.
 """
 import collections
 import csv
@@ -30,7 +30,7 @@ def main():
         name = k.replace("void ", "")[:60]
         lines.append(f"{name:60s} calls {len(v):6d} avg {statistics.mean(v) / 1e3:8.2f} us  total {sum(v) / 1e6:8.2f} ms "
                      f"{100 * sum(v) / total:5.1f}%")
-    lines += ["", f"{DOMINANT} by grid (x = workgroups*512 threads; prefill launches carry one workgroup per row tile and weight tile):"]
+    lines += ["", f"{DOMINANT} by grid (x = workgroups*512 threads):"]
     by = collections.defaultdict(list)
     for r in rows:
         if DOMINANT in r["Kernel_Name"]:
@@ -38,7 +38,7 @@ def main():
     smallest = min(by) if by else None
     for k, v in sorted(by.items()):
         lines.append(f"  grid {k}: calls {len(v):5d} avg {statistics.mean(v) / 1e3:7.2f} us  median {statistics.median(v) / 1e3:7.2f} us"
-                     f"  min {min(v) / 1e3:7.2f} us" + ("   <- the decode launch bench.py times" if k == smallest else "   (prefill: several row tiles)"))
+                     f"  min {min(v) / 1e3:7.2f} us" + ("   <- the decode launch bench.py times" if k == smallest else ""))
     # one steady-state frame: from one predictor_input launch to the next
     idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("predictor_input_kernel")]
     if len(idx) > 3:
