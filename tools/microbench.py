@@ -380,6 +380,38 @@ def rowtrace():
               f"{np.median(b[ok]) - t0:7.0f} max {b[ok].max() - t0:7.0f}  (n={int(ok.sum())})")
 
 
+def prefill_batch():
+    """One engine step that prefills QTTS_PREFILL_SEQS prompts of QTTS_FRAME_PROMPT tokens together (packed rows)."""
+    import json, tempfile
+    sys.path.insert(0, ROOT)
+    import bench
+    from nano_qwen3tts_vllm.llm import TalkerLLM
+    from nano_qwen3tts_vllm.sampling_params import SamplingParams
+    from nano_qwen3tts_vllm.utils import synthetic
+    cfg = synthetic.make_config("1.7B")
+    tw, pw = bench.make_weights(cfg, dev)
+    d = tempfile.mkdtemp()
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+    S = int(os.environ.get("QTTS_PREFILL_SEQS", "8"))
+    talker = TalkerLLM(d, num_kvcache_blocks=4 * S + 4, max_num_seqs=64, max_num_batched_tokens=8192, weights=tw)
+    sp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
+    for plen in [int(v) for v in os.environ.get("QTTS_FRAME_PROMPT", "200").split(",")]:
+        ts = []
+        for rep in range(5):
+            for i in range(S):
+                talker.add_request([torch.randn(1, plen, 2048) * 0.5], sp, request_id=f"r{rep}-{i}")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, _, outs = talker.step_with_outputs()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            assert len(outs) == S, len(outs)
+            for i in range(S):
+                talker.clear_request(f"r{rep}-{i}")
+        print(f"prefill of {S} x {plen} tokens in one step: " + " ".join(f"{v:.2f}" for v in ts) + " ms", flush=True)
+    talker.exit()
+
+
 def prefill():
     """Wall time of a talker prefill (prompt of QTTS_FRAME_PROMPT tokens) through FrameEngine.add_stream."""
     import json, tempfile
@@ -413,4 +445,4 @@ def prefill():
 
 
 if __name__ == "__main__":
-    {"prefill": prefill, "rows": rows, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
+    {"prefill": prefill, "prefill_batch": prefill_batch, "rows": rows, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
