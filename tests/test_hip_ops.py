@@ -299,7 +299,8 @@ def test_linear_fused_variants(hip):
 
 
 @pytest.mark.parametrize("Hq,Hkv,ctxs", [(16, 8, [1, 17, 128, 257, 300, 1024, 0, 512]), (4, 2, [3, 260, 0, 511]), (16, 8, [2, 3, 16]),
-                                         (16, 8, [200, 256, 130, 1]), (8, 8, [250, 140, 129]), (8, 8, [1000] * 5 + [700])])
+                                         (16, 8, [200, 256, 130, 1]), (8, 8, [250, 140, 129]), (8, 8, [1000] * 5 + [700]),
+                                         (16, 8, [300, 384, 129, 7]), (8, 8, [385, 512])])
 def test_attention_decode_fused(hip, Hq, Hkv, ctxs):
     """q/k norm + RoPE + KV store + attention in one launch == the oracle's separate ops."""
     g = torch.Generator().manual_seed(sum(ctxs) + 1)
