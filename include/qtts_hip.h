@@ -72,6 +72,31 @@ int qtts_linear_ws(const void *x, int ldx, const void *w_packed, const void *bia
                    const void *residual, int ldr, void *out, int ldo, int M, int N, int K,
                    void *workspace, size_t workspace_bytes, qtts_stream_t stream);
 
+/* ---- fp8 (e4m3, OCP) weights: an extension, the reference has bf16 weights only.
+ * A weight row is stored as q * scale, q in e4m3, scale the smallest power of two with
+ * max|row| / scale <= 448 — so q * scale is a bf16 number and every fp8 entry point below
+ * returns, bit for bit, what its bf16 counterpart returns on the dequantised weights
+ * bf16(q * scale) (that is how it is tested; against the reference's bf16 weights the
+ * difference is the quantisation itself).  Halves the weight bytes a step streams.
+ * Packed layout: [N/16][K/64][64 lanes][16 B], lane (g, r) = row 16*tile + r, bytes 0..7
+ * the k values 64j + 8g .. +8, bytes 8..15 the k values 64j + 32 + 8g .. +8; N % 16 == 0,
+ * K % 64 == 0 (K % 512 == 0 for the GEMMs); scales[N] per packed row (for gate/up: the
+ * interleaved row order of qtts_pack_gate_up). */
+size_t qtts_packed_weight_fp8_bytes(int N, int K);
+int qtts_pack_weight_fp8(const void *w_rowmajor, void *packed, float *scales, int N, int K,
+                         qtts_stream_t stream);
+int qtts_pack_gate_up_fp8(const void *gate, const void *up, void *packed, float *scales,
+                          int I, int K, qtts_stream_t stream);
+/* qtts_linear / qtts_linear_ws over fp8 weights (workspace as qtts_linear_ws, may be NULL). */
+int qtts_linear_fp8(const void *x, int ldx, const void *w_fp8_packed, const float *w_scales,
+                    const void *bias, const void *residual, int ldr, const void *norm_w,
+                    float eps, void *out, int ldo, int M, int N, int K, void *workspace,
+                    size_t workspace_bytes, qtts_stream_t stream);
+/* qtts_linear_swiglu over fp8 weights. */
+int qtts_linear_swiglu_fp8(const void *x, int ldx, const void *w_gate_up_fp8_packed,
+                           const float *w_scales, const void *norm_w, float eps, void *out,
+                           int ldo, int M, int I, int K, qtts_stream_t stream);
+
 /* out[M,I] = silu(x@Wg^T) * (x@Wu^T) with the reference's two roundings
  * (P/models/qwen3_tts_share.py:131-135, P/layers/activation.py:11-13);
  * optional fused RMSNorm of x as above. */

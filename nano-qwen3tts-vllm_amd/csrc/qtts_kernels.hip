@@ -131,6 +131,63 @@ extern "C" int qtts_pack_gate_up(const void *gate, const void *up, void *packed,
     return QTTS_OK;
 }
 
+// ------------------------------------------------------------------ fp8 (e4m3) weights
+// A weight row is stored as q * scale with q in e4m3 and scale a power of two (so q * scale is a bf16 number and
+// the GEMM over fp8 weights equals, bit for bit, the bf16 GEMM over the dequantised weights).  Layout:
+// [N/16 tiles][K/64][64 lanes][16 bytes]; lane (g, r) of a fragment holds row 16*tile + r, bytes 0..7 the k values
+// 64*j + 8*g .. +8 (the even k-step of the pair), bytes 8..15 the k values 64*j + 32 + 8*g .. +8 (the odd one).
+// scales[packed row].  With `up` != null the packed rows are the gate/up interleave of qtts_pack_gate_up.
+__global__ __launch_bounds__(256) void pack_fp8_kernel(const bf16_t *__restrict__ w, const bf16_t *__restrict__ up,
+                                                       unsigned char *__restrict__ packed, float *__restrict__ scales, int K) {
+    __shared__ float red[4];
+    const int pr = blockIdx.x, tile = pr >> 4, r = pr & 15;
+    const bf16_t *src = !up ? w + (size_t)pr * K : (r < 8 ? w + (size_t)(8 * tile + r) * K : up + (size_t)(8 * tile + r - 8) * K);
+    float amax = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) amax = fmaxf(amax, fabsf(bf2f(src[k])));
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // smallest power of two with amax / scale <= 448
+    float scale = 1.0f;
+    if (amax > 0.f) {
+        int e;
+        const float mant = frexpf(amax / 448.0f, &e);            // amax/448 = mant * 2^e, mant in [0.5, 1)
+        scale = ldexpf(1.0f, mant == 0.5f ? e - 1 : e);
+    }
+    if (threadIdx.x == 0) scales[pr] = scale;
+    const float inv = 1.0f / scale;                              // exact
+    for (int k4 = threadIdx.x * 4; k4 < K; k4 += 1024) {
+        int word = 0;
+        word = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(src[k4]) * inv, bf2f(src[k4 + 1]) * inv, word, false);
+        word = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(src[k4 + 2]) * inv, bf2f(src[k4 + 3]) * inv, word, true);
+        const int j = k4 >> 6, within = k4 & 63, half = within >> 5, g = (within & 31) >> 3, e = within & 7;
+        const size_t off = (((size_t)tile * (K >> 6) + j) * 64 + (g * 16 + r)) * 16 + half * 8 + e;
+        *reinterpret_cast<int *>(packed + off) = word;
+    }
+}
+
+extern "C" size_t qtts_packed_weight_fp8_bytes(int N, int K) { return (size_t)N * K; }
+
+extern "C" int qtts_pack_weight_fp8(const void *w_rowmajor, void *packed, float *scales, int N, int K, qtts_stream_t stream) {
+    QCHECK(w_rowmajor && packed && scales, "pack_weight_fp8: null pointer");
+    QCHECK(N > 0 && K > 0 && N % 16 == 0 && K % 64 == 0, "pack_weight_fp8: need N%%16==0, K%%64==0 (N=%d K=%d)", N, K);
+    hipLaunchKernelGGL(pack_fp8_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)w_rowmajor, nullptr,
+                       (unsigned char *)packed, scales, K);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
+extern "C" int qtts_pack_gate_up_fp8(const void *gate, const void *up, void *packed, float *scales, int I, int K,
+                                     qtts_stream_t stream) {
+    QCHECK(gate && up && packed && scales, "pack_gate_up_fp8: null pointer");
+    QCHECK(I > 0 && K > 0 && I % 8 == 0 && K % 64 == 0, "pack_gate_up_fp8: need I%%8==0, K%%64==0 (I=%d K=%d)", I, K);
+    hipLaunchKernelGGL(pack_fp8_kernel, dim3(2 * I), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)gate,
+                       (const bf16_t *)up, (unsigned char *)packed, scales, K);
+    QLAUNCH();
+    return QTTS_OK;
+}
+
 static int g_tune_ksw = 0;   // 0 = automatic
 static int g_tune_t = 0;
 static int g_dbg_linear = 0;
@@ -160,8 +217,21 @@ struct LinArgs {
     bf16_t *xnorm_out; int ldxn;
     bf16_t *out; int ldo;
     int M, N, K, tiles_per_wg;
+    const float *wscale = nullptr;   // non-null: wp holds fp8 (e4m3) weights, two k-steps per 16-byte fragment; scale per packed row
     int dbg;      // bit0: tuning experiment (every tile reads weight tile 0); bits 8+: row-tile count of a prefill launch
 };
+
+// 16 fp8 (e4m3, OCP) values -> two bf16 fragments, exactly (every e4m3 value is a bf16 value).  Bytes 0..7 belong
+// to the even k-step of the pair, bytes 8..15 to the odd one.
+typedef float float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t fp8x2_to_bf16x2(uint32_t w, bool hi) {
+    const float2_t f = hi ? __builtin_amdgcn_cvt_pk_f32_fp8(w, true) : __builtin_amdgcn_cvt_pk_f32_fp8(w, false);
+    return (__float_as_uint(f[0]) >> 16) | (__float_as_uint(f[1]) & 0xffff0000u);
+}
+__device__ __forceinline__ void fp8x16_to_bf16(const uint4 q, Frag &even, Frag &odd) {
+    even.u = make_uint4(fp8x2_to_bf16x2(q.x, false), fp8x2_to_bf16x2(q.x, true), fp8x2_to_bf16x2(q.y, false), fp8x2_to_bf16x2(q.y, true));
+    odd.u = make_uint4(fp8x2_to_bf16x2(q.z, false), fp8x2_to_bf16x2(q.z, true), fp8x2_to_bf16x2(q.w, false), fp8x2_to_bf16x2(q.w, true));
+}
 
 __device__ __forceinline__ void unpack2(uint32_t w, float &a, float &b) {
     a = __uint_as_float(w << 16);
@@ -181,10 +251,11 @@ struct LinTail {
     bf16_t *xnorm_out; int ldxn;
     bf16_t *out; int ldo;
     long long *trace;     // tuning experiments only (null in production): 4 timestamps per workgroup
+    const float *wscale;  // fp8 weights: one power-of-two scale per packed weight row
 };
 #define QTTS_TRACE(slot) do { if (tl.trace && threadIdx.x == 0) tl.trace[(size_t)blockIdx.x * 4 + (slot)] = wall_clock64(); } while (0)
 
-template <int KSW, int PRO, bool DB, int EPI, bool SUB = false>
+template <int KSW, int PRO, bool DB, int EPI, bool SUB = false, bool W8 = false>
 __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uint4 *wp, const int64_t *ids, int ldx, int K,
                                                       int N, int M, int tiles_per_wg, int dbg, int id_rows,
                                                       const bf16_t *nw, float eps, const LinTail tl) {
@@ -200,6 +271,9 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     const int NW = blockDim.x >> 6;
     const int g = lane >> 4, r = lane & 15;
     const int KS = p.K >> 5;
+    // W8: the weights are fp8 (e4m3), one 16-byte fragment per lane covers TWO k-steps; NLD loads per tile
+    constexpr int NLD = W8 ? KSW / 2 : KSW;
+    const int KSP = W8 ? KS >> 1 : KS;
     // Several row tiles (prefill): the launch is one-dimensional and the workgroups that share a weight tile are
     // placed on the same XCD, next to each other in dispatch order (workgroup i runs on XCD i % 8), so the tile
     // comes from HBM once and the other row tiles find it in that XCD's L2.
@@ -267,11 +341,12 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
 #pragma unroll
         for (int i = 0; i < KSW; ++i) nwv[i] = *reinterpret_cast<const uint4 *>(p.nw + 32 * (ks0 + i) + 8 * g);
     }
-    Frag a[DB ? 2 : 1][KSW];
+    const int kp0 = W8 ? ks0 >> 1 : ks0;
+    Frag a[DB ? 2 : 1][NLD];
     {
-        const uint4 *wptr = p.wp + ((size_t)((p.dbg & 1) ? 0 : t_begin) * KS + ks0) * 64 + lane;
+        const uint4 *wptr = p.wp + ((size_t)((p.dbg & 1) ? 0 : t_begin) * KSP + kp0) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < KSW; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             if (arow) a[0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
             else a[0][i].u = make_uint4(0, 0, 0, 0);
         }
@@ -280,10 +355,10 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             // after next as soon as its multiplication is issued (the last tile is requested again at the end,
             // which keeps the code free of branches so that the compiler's wait counts stay exact)
             const bool two = t_begin + 1 < t_end;
-            const uint4 *wptr1 = p.wp + ((size_t)((p.dbg & 1) || !two ? 0 : t_begin + 1) * KS + (two ? ks0 : 0)) * 64 + lane;
+            const uint4 *wptr1 = p.wp + ((size_t)((p.dbg & 1) || !two ? 0 : t_begin + 1) * KSP + (two ? kp0 : 0)) * 64 + lane;
             const int wstep1 = two ? 64 : 0;
 #pragma unroll
-            for (int i = 0; i < KSW; ++i)
+            for (int i = 0; i < NLD; ++i)
                 a[DB ? 1 : 0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr1 + i * wstep1));
         }
     }
@@ -340,12 +415,19 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         // past the last tile the refills still execute (no branch) but all read one 1 KiB fragment that is in
         // the cache already
         const bool more = t + 2 < t_end;
-        const uint4 *wnext = p.wp + ((size_t)((p.dbg & 1) || !more ? 0 : t + 2) * KS + (more ? ks0 : 0)) * 64 + lane;
+        const uint4 *wnext = p.wp + ((size_t)((p.dbg & 1) || !more ? 0 : t + 2) * KSP + (more ? kp0 : 0)) * 64 + lane;
         const int wstep = more ? 64 : 0;
         float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < KSW; ++i) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[DB ? cur : 0][i].v, xb[i].v, acc, 0, 0, 0);
+        for (int i = 0; i < NLD; ++i) {
+            if (W8) {
+                Frag f0, f1;
+                fp8x16_to_bf16(a[DB ? cur : 0][i].u, f0, f1);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0.v, xb[2 * i].v, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1.v, xb[W8 ? 2 * i + 1 : 0].v, acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[DB ? cur : 0][i].v, xb[i].v, acc, 0, 0, 0);
+            }
             if (DB) a[DB ? cur : 0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wnext + i * wstep));
         }
         float4_t *red = smem4 + (size_t)(it & 1) * NW * 64;
@@ -356,10 +438,13 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         if (wave == 0) {
             float4_t sum = red[lane];
             for (int w = 1; w < NW; ++w) sum += red[w * 64 + lane];
+            // fp8 weights: the row's power-of-two scale, exact in fp32 (same result as bf16 weights q * scale)
+            if (W8) sum *= *reinterpret_cast<const float4_t *>(tl.wscale + 16 * t + 4 * g);
             if (EPI == 1) {
                 if (g < 2) {                              // lanes 0..31 hold gate rows; the up rows sit 32 lanes on
                     float4_t ups = red[lane + 32];
                     for (int w = 1; w < NW; ++w) ups += red[w * 64 + lane + 32];
+                    if (W8) ups *= *reinterpret_cast<const float4_t *>(tl.wscale + 16 * t + 8 + 4 * g);
                     if (mvalid) {
                         float v[4];
 #pragma unroll
@@ -427,10 +512,11 @@ struct RowsArgs {
     bf16_t *out; int ldo;
     float *part; int mpad;       // EPI 2: part[kpart][mpad][N]
     int rgroups, KS;             // row groups of TM tiles; k-steps of a whole packed weight tile
+    const float *wscale;         // fp8 weights: scale per packed weight row
     long long *trace;            // tuning experiments only (null in production): 32 timestamps per workgroup
 };
 
-template <int KSW, int TM, int EPI>
+template <int KSW, int TM, int EPI, bool W8 = false>
 __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const uint4 *wp, int ldx, int N, int M,
                                                           int tiles_per_wg, const RowsArgs p) {
 #define QTTS_RTRACE(slot) do { if (p.trace && threadIdx.x == 0 && (slot) < 32) p.trace[(size_t)blockIdx.x * 32 + (slot)] = wall_clock64(); } while (0)
@@ -449,6 +535,9 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
     if (t_begin >= ntiles) return;
     const int t_end = min(t_begin + tiles_per_wg, ntiles);
     const int ks0 = blockIdx.y * (NW * KSW) + wave * KSW;
+    // W8: fp8 weights, one 16-byte fragment per lane covers two k-steps
+    constexpr int NLD = W8 ? KSW / 2 : KSW;
+    const int KSP = W8 ? p.KS >> 1 : p.KS, kp0 = W8 ? ks0 >> 1 : ks0;
 
     // rows beyond M read row 0: their accumulator columns are never stored
     Frag xb[TM][KSW];
@@ -462,14 +551,14 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
     // Two weight tiles are in flight: a fragment register is refilled with the tile after next as soon as its
     // multiplications are issued, so the loads of tile t+2 go out while tile t is still being multiplied.
     const int nt = t_end - t_begin;
-    Frag a[2][KSW];
+    Frag a[2][NLD];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const bool have = j < nt;
-        const uint4 *wptr = wp + ((size_t)(have ? t_begin + j : 0) * p.KS + (have ? ks0 : 0)) * 64 + lane;
+        const uint4 *wptr = wp + ((size_t)(have ? t_begin + j : 0) * KSP + (have ? kp0 : 0)) * 64 + lane;
         const int wstep0 = have ? 64 : 0;
 #pragma unroll
-        for (int k = 0; k < KSW; ++k) a[j][k].u = wptr[k * wstep0];
+        for (int k = 0; k < NLD; ++k) a[j][k].u = wptr[k * wstep0];
     }
     auto tile_body = [&](const int cur, const int it) {
         const int t = t_begin + it;
@@ -481,16 +570,26 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
         // unconditional: with straight-line code the compiler's wait counts let exactly the younger tile's loads
         // stay in flight; past the last tile the refills all read one 1 KiB fragment that is cached already
         const bool more = it + 2 < nt;
-        const uint4 *wnext = wp + ((size_t)(more ? t + 2 : 0) * p.KS + (more ? ks0 : 0)) * 64 + lane;
+        const uint4 *wnext = wp + ((size_t)(more ? t + 2 : 0) * KSP + (more ? kp0 : 0)) * 64 + lane;
         const int wstep = more ? 64 : 0;
         float4_t acc[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) acc[i] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < KSW; ++k) {
+        for (int k = 0; k < NLD; ++k) {
+            if (W8) {
+                Frag f0, f1;
+                fp8x16_to_bf16(a[cur][k].u, f0, f1);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][k].v, xb[i][k].v, acc[i], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0.v, xb[i][2 * k].v, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1.v, xb[i][W8 ? 2 * k + 1 : 0].v, acc[i], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][k].v, xb[i][k].v, acc[i], 0, 0, 0);
+            }
             a[cur][k].u = wnext[k * wstep];
         }
         float4_t *red = smem4 + (size_t)(it & 1) * NW * TM * 64;
@@ -505,6 +604,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
         const int m = (by * TM + wave) * 16 + r;
         float4_t sum = mine[lane];
         for (int w = 1; w < NW; ++w) sum += mine[w * TM * 64 + lane];
+        if (W8) sum *= *reinterpret_cast<const float4_t *>(p.wscale + 16 * t + 4 * g);     // exact: powers of two
         if (EPI == 2) {
             if (m < M)
                 *reinterpret_cast<float4_t *>(p.part + ((size_t)blockIdx.y * p.mpad + m) * N + 16 * t + 4 * g) = sum;
@@ -514,6 +614,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
             if (g < 2) {                                  // lanes 0..31 hold gate rows; the up rows sit 32 lanes on
                 float4_t ups = mine[lane + 32];
                 for (int w = 1; w < NW; ++w) ups += mine[w * TM * 64 + lane + 32];
+                if (W8) ups *= *reinterpret_cast<const float4_t *>(p.wscale + 16 * t + 8 + 4 * g);
                 if (m < M) {
                     float v[4];
 #pragma unroll
@@ -605,6 +706,14 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
         tl.trace = g_trace + (size_t)g_trace_launch * 4 * 1024;      // up to 1024 workgroups per traced launch
         ++g_trace_launch;
     }
+    tl.wscale = a.wscale;
+    if constexpr (KSW % 2 == 0 && PRO != 2) {
+        if (a.wscale) {
+            hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI, SUB, true>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids,
+                               a.ldx, a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
+            return;
+        }
+    }
     hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI, SUB>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids, a.ldx,
                        a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
 }
@@ -617,6 +726,16 @@ static void launch_rows_inst(dim3 grid, hipStream_t s, const LinArgs &a, int tpw
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_rows_kernel<KSW, TM, EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         once = true;
+    }
+    if (a.wscale) {
+        static bool once8 = false;
+        if (!once8) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_rows_kernel<KSW, TM, EPI, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            once8 = true;
+        }
+        hipLaunchKernelGGL((linear_rows_kernel<KSW, TM, EPI, true>), grid, dim3(512), shmem, s, a.x, a.wp, a.ldx, a.N, a.M, tpw, r);
+        return;
     }
     hipLaunchKernelGGL((linear_rows_kernel<KSW, TM, EPI>), grid, dim3(512), shmem, s, a.x, a.wp, a.ldx, a.N, a.M, tpw, r);
 }
@@ -648,6 +767,7 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     r.bias = a.bias; r.res = a.res; r.ldr = a.ldr; r.out = a.out; r.ldo = a.ldo;
     r.part = scratch; r.mpad = a.M; r.rgroups = (mtiles + TM - 1) / TM; r.KS = KS;
     r.trace = g_trace;
+    r.wscale = a.wscale;
     const int ntiles = a.N / 16;
     // One round of workgroups (a CU holds one, an XCD 32): workgroup i runs on XCD i % 8 and the launch is laid out
     // in groups of 8 column blocks x all row groups (x K parts), so the groups of 8 that fit one round are
@@ -700,6 +820,7 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
         for (int c : ksws) if (c == g_tune_ksw) KSW = c;
     QCHECK(KSW > 0, "linear: K=%d not supported (K/32 must factor as <=8 waves x {1,2,4,6,8,12,24})", a.K);
     QCHECK(!(pro == 1 && KSW == 24), "linear: RMSNorm prologue not supported for K=%d", a.K);
+    QCHECK(!a.wscale || (KSW % 2 == 0 && pro != 2 && a.K % 64 == 0), "linear: fp8 weights need K %% 512 == 0 and no SwiGLU prologue (K=%d)", a.K);
     const int NW = KS / KSW;
     const int ntiles = a.N / 16;
     int tpw = 1;
@@ -800,6 +921,33 @@ extern "C" int qtts_linear_swiglu(const void *x, int ldx, const void *w_gate_up_
     LinArgs a;
     a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0;
     a.wp = (const uint4 *)w_gate_up_packed; a.bias = nullptr; a.res = nullptr; a.ldr = 0;
+    a.nw = (const bf16_t *)norm_w; a.eps = eps; a.xnorm_out = nullptr; a.ldxn = 0;
+    a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = 2 * I; a.K = K; a.tiles_per_wg = 1;
+    return launch_linear2(a, norm_w ? 1 : 0, (hipStream_t)stream, true);
+}
+
+extern "C" int qtts_linear_fp8(const void *x, int ldx, const void *w_fp8_packed, const float *w_scales, const void *bias,
+                               const void *residual, int ldr, const void *norm_w, float eps, void *out, int ldo, int M, int N,
+                               int K, void *workspace, size_t workspace_bytes, qtts_stream_t stream) {
+    QCHECK(w_scales, "linear_fp8: null scales");
+    QCHECK(!workspace || ((uintptr_t)workspace & 15) == 0, "linear_fp8: workspace must be 16-byte aligned");
+    LinArgs a;
+    a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0;
+    a.wp = (const uint4 *)w_fp8_packed; a.wscale = w_scales; a.bias = (const bf16_t *)bias; a.res = (const bf16_t *)residual;
+    a.ldr = ldr; a.nw = (const bf16_t *)norm_w; a.eps = eps; a.xnorm_out = nullptr; a.ldxn = 0;
+    a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.tiles_per_wg = 1;
+    return launch_linear2(a, norm_w ? 1 : 0, (hipStream_t)stream, false, (float *)workspace, workspace_bytes);
+}
+
+extern "C" int qtts_linear_swiglu_fp8(const void *x, int ldx, const void *w_gate_up_fp8_packed, const float *w_scales,
+                                      const void *norm_w, float eps, void *out, int ldo, int M, int I, int K,
+                                      qtts_stream_t stream) {
+    QCHECK(w_scales, "linear_swiglu_fp8: null scales");
+    QCHECK(I > 0 && I % 8 == 0, "linear_swiglu_fp8: I=%d must be a multiple of 8", I);
+    QCHECK(ldo >= I, "linear_swiglu_fp8: out row stride %d < I=%d", ldo, I);
+    LinArgs a;
+    a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0;
+    a.wp = (const uint4 *)w_gate_up_fp8_packed; a.wscale = w_scales; a.bias = nullptr; a.res = nullptr; a.ldr = 0;
     a.nw = (const bf16_t *)norm_w; a.eps = eps; a.xnorm_out = nullptr; a.ldxn = 0;
     a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = 2 * I; a.K = K; a.tiles_per_wg = 1;
     return launch_linear2(a, norm_w ? 1 : 0, (hipStream_t)stream, true);

@@ -36,6 +36,11 @@ _SIGS = {
     "qtts_model_forward_logits": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "qtts_linear_workspace_bytes": (_sz, [_i, _i, _i]),
     "qtts_linear_ws": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "qtts_packed_weight_fp8_bytes": (_sz, [_i, _i]),
+    "qtts_pack_weight_fp8": (_i, [_p, _p, _p, _i, _i, _p]),
+    "qtts_pack_gate_up_fp8": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "qtts_linear_fp8": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _f, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "qtts_linear_swiglu_fp8": (_i, [_p, _i, _p, _p, _p, _f, _p, _i, _i, _i, _i, _p]),
     "qtts_linear_swiglu": (_i, [_p, _i, _p, _p, _f, _p, _i, _i, _i, _i, _p]),
     "qtts_rmsnorm": (_i, [_p, _i, _p, _f, _p, _i, _i, _i, _p]),
     "qtts_qknorm_rope_store": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
@@ -124,6 +129,46 @@ def linear(x, w_packed, N, bias=None, residual=None, norm_w=None, eps=1e-6, out=
     check(lib.qtts_linear(ptr(x), x.stride(0), ptr(w_packed), ptr(bias), ptr(residual),
                           residual.stride(0) if residual is not None else 0, ptr(norm_w), eps,
                           ptr(out), out.stride(0), M, N, K, stream()), "linear")
+    return out
+
+
+def pack_weight_fp8(w: torch.Tensor):
+    """[N, K] bf16 -> (fp8 fragments as uint8 [N*K], fp32 power-of-two scale per row)."""
+    assert w.dtype == torch.bfloat16 and w.is_contiguous()
+    N, K = w.shape
+    packed = torch.empty(N * K, dtype=torch.uint8, device=w.device)
+    scales = torch.empty(N, dtype=torch.float32, device=w.device)
+    check(lib.qtts_pack_weight_fp8(ptr(w), ptr(packed), ptr(scales), N, K, stream()), "pack_weight_fp8")
+    return packed, scales
+
+
+def pack_gate_up_fp8(gate: torch.Tensor, up: torch.Tensor):
+    assert gate.shape == up.shape and gate.is_contiguous() and up.is_contiguous()
+    I, K = gate.shape
+    packed = torch.empty(2 * I * K, dtype=torch.uint8, device=gate.device)
+    scales = torch.empty(2 * I, dtype=torch.float32, device=gate.device)
+    check(lib.qtts_pack_gate_up_fp8(ptr(gate), ptr(up), ptr(packed), ptr(scales), I, K, stream()), "pack_gate_up_fp8")
+    return packed, scales
+
+
+def linear_fp8(x, w_packed, w_scales, N, bias=None, residual=None, norm_w=None, eps=1e-6, out=None):
+    M, K = x.shape
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    nbytes = int(lib.qtts_linear_workspace_bytes(M, N, K)) if norm_w is None else 0
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    check(lib.qtts_linear_fp8(ptr(x), x.stride(0), ptr(w_packed), ptr(w_scales), ptr(bias), ptr(residual),
+                              residual.stride(0) if residual is not None else 0, ptr(norm_w), eps, ptr(out),
+                              out.stride(0), M, N, K, ptr(ws), nbytes, stream()), "linear_fp8")
+    return out
+
+
+def linear_swiglu_fp8(x, w_gu_packed, w_scales, I, norm_w=None, eps=1e-6, out=None):
+    M, K = x.shape
+    if out is None:
+        out = torch.empty(M, I, dtype=torch.bfloat16, device=x.device)
+    check(lib.qtts_linear_swiglu_fp8(ptr(x), x.stride(0), ptr(w_gu_packed), ptr(w_scales), ptr(norm_w), eps, ptr(out),
+                                     out.stride(0), M, I, K, stream()), "linear_swiglu_fp8")
     return out
 
 

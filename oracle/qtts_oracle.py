@@ -407,3 +407,18 @@ def frame_loop(tw, tcfg, pw, pcfg, prompts, text_adds, n_frames, num_blocks=32):
         if f + 1 < n_frames:
             tok, hid, logits = talker.decode(seqs, torch.stack(nxt, 0))
     return frames, margins, pick_margins
+
+
+def quantize_fp8_rows(w: torch.Tensor):
+    """Weight-only fp8 (e4m3, OCP) with one power-of-two scale per row — the arithmetic of the build's fp8
+    extension (the reference has bf16 weights only).  Returns (q as float8_e4m3fn, scale fp32 [N], the dequantised
+    weights q * scale as bf16, exact): scale is the smallest power of two with max|row| / scale <= 448."""
+    wf = w.float()
+    amax = wf.abs().amax(dim=1)
+    mant, exp = torch.frexp(amax / 448.0)
+    exp = torch.where(mant == 0.5, exp - 1, exp)
+    scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), exp), torch.ones_like(amax))
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    deq = (q.float() * scale[:, None]).to(torch.bfloat16)
+    assert torch.equal(deq.float(), q.float() * scale[:, None])
+    return q, scale, deq

@@ -433,3 +433,71 @@ def test_linear_prefill_row_counts(hip, M, N, K, kind):
             assert float((diff > 0).float().mean()) <= 0.02
             return
     assert_bf16_close(got, want, what=f"rows {kind}")
+
+
+def _fp8_unpack(packed: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    """Bytes of the fragment layout back to row-major [N, K] (uint8)."""
+    b = packed.cpu().view(N // 16, K // 64, 4, 16, 2, 8)             # tile, j, g, r, half, e
+    return b.permute(0, 3, 1, 4, 2, 5).reshape(N, K)                  # tile, r, j, half, g, e
+
+
+def test_fp8_pack_matches_torch_quantisation(hip):
+    """Device packing == the oracle's quantisation (e4m3 OCP encoding, round to nearest even, power-of-two row
+    scales), including an all-zero row, a row whose maximum is exactly 448 * 2^k and tiny values."""
+    g = torch.Generator().manual_seed(5)
+    N, K = 64, 512
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    w[3] = 0
+    w[5, 7] = 448.0 * 2.0 ** -6
+    w[5] = w[5].clamp(-7.0, 7.0)
+    w[9] *= 1e-3
+    w[11] *= 300.0
+    q, scale, deq = O.quantize_fp8_rows(w)
+    packed, scales = hip.pack_weight_fp8(w.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(scales.cpu(), scale)
+    assert torch.equal(_fp8_unpack(packed, N, K), q.view(torch.uint8))
+    # gate/up interleave
+    gate, up = w[:32].contiguous(), w[32:].contiguous()
+    pgu, sgu = hip.pack_gate_up_fp8(gate.to(DEV), up.to(DEV))
+    rows = torch.cat([torch.cat([gate[8 * t:8 * t + 8], up[8 * t:8 * t + 8]]) for t in range(4)])
+    q2, s2, _ = O.quantize_fp8_rows(rows)
+    assert torch.equal(sgu.cpu(), s2) and torch.equal(_fp8_unpack(pgu, 64, K), q2.view(torch.uint8))
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(8, 4096, 2048, "plain"), (8, 2048, 2048, "res"), (3, 1024, 3072, "bias"), (8, 2048, 6144, "res"),
+                                        (16, 12288, 2048, "norm"), (8, 4096, 1024, "norm"), (1, 512, 512, "plain"),
+                                        (8, 6144, 2048, "swiglu"), (8, 3072, 1024, "swiglu"), (5, 12288, 2048, "swiglu_plain"),
+                                        (200, 4096, 2048, "plain"), (40, 2048, 2048, "res"), (200, 2048, 6144, "res"),
+                                        (130, 1024, 3072, "bias"), (200, 6144, 2048, "swiglu_plain"), (32, 6144, 1024, "swiglu_plain"),
+                                        (128, 12288, 2048, "swiglu_plain")])
+def test_linear_fp8_equals_bf16_on_dequantised_weights(hip, M, N, K, kind):
+    """Every GEMM variant over fp8 weights returns bit for bit what the bf16 kernel returns on the dequantised
+    weights q * scale (which are bf16 numbers), and the dequantised weights are the oracle's."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().to(DEV)
+    res = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g).bfloat16().to(DEV)
+    if kind.startswith("swiglu"):
+        I = N // 2
+        wg = (torch.randn(I, K, generator=g) * 0.05).bfloat16()
+        wu = (torch.randn(I, K, generator=g) * 0.05).bfloat16()
+        pq, sq = hip.pack_gate_up_fp8(wg.to(DEV), wu.to(DEV))
+        dg, du = O.quantize_fp8_rows(wg)[2], O.quantize_fp8_rows(wu)[2]
+        norm = nw if kind == "swiglu" else None
+        got = hip.linear_swiglu_fp8(x, pq, sq, I, norm_w=norm)
+        want = hip.linear_swiglu(x, hip.pack_gate_up(dg.to(DEV), du.to(DEV)), I, norm_w=norm)
+    else:
+        w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+        pq, sq = hip.pack_weight_fp8(w.to(DEV))
+        wp = hip.pack_weight(O.quantize_fp8_rows(w)[2].to(DEV))
+        kw = dict(bias=bias if kind == "bias" else None, residual=res if kind in ("res", "bias") else None,
+                  norm_w=nw if kind == "norm" else None)
+        got = hip.linear_fp8(x, pq, sq, N, **kw)
+        if kind != "norm" and M > 16:
+            want = hip.linear_ws(x, wp, N, bias=kw["bias"], residual=kw["residual"])
+        else:
+            want = hip.linear(x, wp, N, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
