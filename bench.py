@@ -42,9 +42,10 @@ def make_weights(cfg, device, seed=1234):
     return synthetic.split_state_dict(sd)
 
 
-def algorithmic_bytes_per_frame(cfg, B, mean_ctx):
+def algorithmic_bytes_per_frame(cfg, B, mean_ctx, weights="bf16"):
     """Bytes one frame must move: every talker weight once, the predictor's per-step weights
-    15 times, plus the KV rows attention reads (bf16)."""
+    15 times, plus the KV rows attention reads (bf16).  With fp8 weights the layers' projection
+    matrices count one byte per element (+ 4 bytes of scale per row, neglected)."""
     from nano_qwen3tts_vllm.utils import synthetic
     shapes = synthetic.checkpoint_shapes(cfg)
     numel = lambda k: int(torch.tensor(shapes[k]).prod())
@@ -61,6 +62,10 @@ def algorithmic_bytes_per_frame(cfg, B, mean_ctx):
     kv_p = 2 * p["num_hidden_layers"] * p["num_key_value_heads"] * p["head_dim"] * 2
     n_gen = p["num_code_groups"] - 1
     pred_ctx = sum(range(2, 2 + n_gen))          # 2..16 cached positions read over the burst
+    if weights == "fp8":
+        proj = lambda pre: sum(numel(k) for k in shapes if k.startswith(pre) and "_proj.weight" in k)
+        tproj, pproj = proj("talker.model.layers."), proj("talker.code_predictor.model.layers.")
+        return (2 * talker - tproj) + n_gen * (2 * pred_step - pproj) + B * mean_ctx * kv_t + B * pred_ctx * kv_p
     return 2 * talker + 2 * n_gen * pred_step + B * mean_ctx * kv_t + B * pred_ctx * kv_p
 
 
@@ -74,22 +79,30 @@ def time_dominant_kernel(fe, B, rounds=20):
     x = torch.randn(B, H, device=tr.device).to(torch.bfloat16)
     out = torch.empty(B, I, dtype=torch.bfloat16, device=tr.device)
     # packed gate/up tensors are the 2*I*H-element buffers the decoder keeps
-    packed = [t for t in tr.decoder._keep if t.dim() == 1 and t.numel() == 2 * I * H]
+    packed = tr.decoder.packed_gate_up
+    fp8 = tr.decoder.weight_dtype == "fp8"
+    scales = tr.decoder.gate_up_scales if fp8 else [None] * len(packed)
     norm = tr.decoder.final_norm
     assert len(packed) == tr.shape.num_layers
-    with fe.tr.on_stream():
-        for w in packed:
+
+    def launch(w, sc):
+        if fp8:
+            hip.linear_swiglu_fp8(x, w, sc, I, norm_w=norm, out=out)
+        else:
             hip.linear_swiglu(x, w, I, norm_w=norm, out=out)
+    with fe.tr.on_stream():
+        for w, sc in zip(packed, scales):
+            launch(w, sc)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(rounds):
-            for w in packed:
-                hip.linear_swiglu(x, w, I, norm_w=norm, out=out)
+            for w, sc in zip(packed, scales):
+                launch(w, sc)
         e1.record()
         e1.synchronize()
     n = rounds * len(packed)
     sec = e0.elapsed_time(e1) * 1e-3 / n
-    return sec, 2 * I * H * 2 + B * H * 2 + B * I * 2
+    return sec, 2 * I * H * (1 if fp8 else 2) + (2 * I * 4 if fp8 else 0) + B * H * 2 + B * I * 2
 
 
 def cpu_baseline(cfg, tw, pw, B, frames, prompt_len):
@@ -153,10 +166,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=8)
     ap.add_argument("--size", default="1.7B")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: the layers' GEMM weights as e4m3 with power-of-two row scales (an extension; not the contract line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=40)
     args = ap.parse_args()
 
+    os.environ["QTTS_WEIGHT_DTYPE"] = args.weights
     rank, world, local = dist_env()
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     # Rehearsal on a box with fewer GPUs than ranks (QTTS_BENCH_REHEARSAL=1): every rank uses GPU 0 and the
@@ -228,16 +244,17 @@ def main():
         tokens = whole_job_tokens(B, args.steps, world)
         value = tokens / elapsed
         mean_ctx = sum(prompt_lens) / B + 1 + args.warmup + 1 + args.steps / 2
-        bytes_frame = algorithmic_bytes_per_frame(cfg, B, mean_ctx)
+        bytes_frame = algorithmic_bytes_per_frame(cfg, B, mean_ctx, args.weights)
         ksec, kbytes = time_dominant_kernel(fe, B)
         out = {
             "metric": "codec tokens/sec at 8 concurrent streams per GPU (RTF alongside), Qwen3-TTS-1.7B",
             "value": value, "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16" if args.weights == "bf16" else "bf16 (weights stored as fp8 e4m3, converted in registers)",
+            "data": "synthetic",
             "config": {"workload": f"Qwen3-TTS-12Hz-{args.size} shapes, {B} concurrent streams per GPU, greedy, "
                                    f"continuous decode with one hipGraph per frame; prompts {prompt_lens} tokens, "
-                                   f"random-init weights" + (" [REHEARSAL: all ranks on one GPU]" if rehearsal else ""),
+                                   f"random-init weights" + (", fp8 weights" if args.weights == "fp8" else "") + (" [REHEARSAL: all ranks on one GPU]" if rehearsal else ""),
                        "streams_per_gpu": B, "replicas": world},
             "rtf": ms_per_step * 1e-3 / FRAME_SECONDS,
             "first_chunk_ms_p50": statistics.median(first_frame_ms) + frame0_ms,
@@ -247,7 +264,8 @@ def main():
                                "unit": "GB/s", "frac": bytes_frame / (ms_per_step * 1e-3) / HBM_PEAK},
             "roofline": {"bound": "hbm", "kernel": "linear2_kernel<8,1,true,1> (talker RMSNorm + gate/up GEMM + SwiGLU launch)",
                          "achieved": kbytes / ksec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": kbytes / ksec / HBM_PEAK, "traffic": pmc_traffic(), "bytes_per_launch": kbytes,
+                         "frac": kbytes / ksec / HBM_PEAK, "traffic": pmc_traffic() if args.weights == "bf16" else None,
+                         "bytes_per_launch": kbytes,
                          "us_per_launch": ksec * 1e6},
         }
         if not args.no_cpu_baseline:

@@ -234,6 +234,14 @@ int qtts_model_set_layer(qtts_model_t *m, int layer, const void *input_norm_w,
                          const void *wqkv_packed, const void *q_norm_w, const void *k_norm_w,
                          const void *wo_packed, const void *post_norm_w,
                          const void *w_gate_up_packed, const void *w_down_packed);
+/* qtts_model_set_layer with the four GEMM weights as fp8 (qtts_pack_weight_fp8 / qtts_pack_gate_up_fp8) and their
+ * row scales; hidden and intermediate size must be multiples of 512.  No counterpart in the reference. */
+int qtts_model_set_layer_fp8(qtts_model_t *m, int layer, const void *input_norm_w, const void *wqkv_fp8,
+                             const float *wqkv_scales, const void *q_norm_w, const void *k_norm_w,
+                             const void *wo_fp8, const float *wo_scales, const void *post_norm_w,
+                             const void *w_gate_up_fp8, const float *w_gate_up_scales,
+                             const void *w_down_fp8, const float *w_down_scales);
+
 int qtts_model_set_final_norm(qtts_model_t *m, const void *w);
 int qtts_model_set_rope(qtts_model_t *m, const void *cos, const void *sin, int max_pos);
 /* kv: [2, n_layers, num_blocks, 256, n_kv_heads, 128] bf16 (P/engine/model_runner/base.py:158-164). */

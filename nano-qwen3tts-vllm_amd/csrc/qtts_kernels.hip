@@ -2077,7 +2077,29 @@ extern "C" int qtts_advance_decode(int64_t *positions, int32_t *slot_mapping, in
 struct LayerW {
     const void *in_norm = nullptr, *wqkv = nullptr, *q_norm = nullptr, *k_norm = nullptr, *wo = nullptr,
                *post_norm = nullptr, *wgu = nullptr, *wdown = nullptr;
+    // fp8 weights: scale per packed row of the four GEMM weights (all null: bf16 weights)
+    const float *s_qkv = nullptr, *s_o = nullptr, *s_gu = nullptr, *s_down = nullptr;
 };
+
+// The decoder stack's GEMMs with bf16 or fp8 weights (wscale != null).
+static int stack_linear(const void *x, int ldx, const void *w, const float *wscale, const void *residual, int ldr,
+                        const void *norm_w, float eps, void *out, int ldo, int M, int N, int K, float *scratch,
+                        size_t scratch_bytes, qtts_stream_t stream) {
+    LinArgs a;
+    a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0; a.wp = (const uint4 *)w; a.wscale = wscale;
+    a.bias = nullptr; a.res = (const bf16_t *)residual; a.ldr = ldr; a.nw = (const bf16_t *)norm_w; a.eps = eps;
+    a.xnorm_out = nullptr; a.ldxn = 0; a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.tiles_per_wg = 1;
+    return launch_linear2(a, norm_w ? 1 : 0, (hipStream_t)stream, false, scratch, scratch_bytes);
+}
+
+static int stack_swiglu(const void *x, int ldx, const void *wgu, const float *wscale, const void *norm_w, float eps,
+                        void *out, int ldo, int M, int I, int K, qtts_stream_t stream) {
+    LinArgs a;
+    a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0; a.wp = (const uint4 *)wgu; a.wscale = wscale;
+    a.bias = nullptr; a.res = nullptr; a.ldr = 0; a.nw = (const bf16_t *)norm_w; a.eps = eps; a.xnorm_out = nullptr;
+    a.ldxn = 0; a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = 2 * I; a.K = K; a.tiles_per_wg = 1;
+    return launch_linear2(a, norm_w ? 1 : 0, (hipStream_t)stream, true);
+}
 
 struct qtts_model {
     int hidden, n_layers, n_heads, n_kv_heads, head_dim, inter;
@@ -2129,6 +2151,22 @@ extern "C" int qtts_model_set_layer(qtts_model_t *m, int layer, const void *inpu
     L.post_norm = post_norm_w;
     L.wgu = w_gate_up_packed;
     L.wdown = w_down_packed;
+    L.s_qkv = L.s_o = L.s_gu = L.s_down = nullptr;
+    return QTTS_OK;
+}
+
+extern "C" int qtts_model_set_layer_fp8(qtts_model_t *m, int layer, const void *input_norm_w, const void *wqkv_fp8,
+                                        const float *wqkv_scales, const void *q_norm_w, const void *k_norm_w,
+                                        const void *wo_fp8, const float *wo_scales, const void *post_norm_w,
+                                        const void *w_gate_up_fp8, const float *w_gate_up_scales, const void *w_down_fp8,
+                                        const float *w_down_scales) {
+    QCHECK(wqkv_scales && wo_scales && w_gate_up_scales && w_down_scales, "model_set_layer_fp8: null scales");
+    QCHECK(m && m->hidden % 512 == 0 && m->inter % 512 == 0, "model_set_layer_fp8: hidden and intermediate size must be multiples of 512");
+    int rc = qtts_model_set_layer(m, layer, input_norm_w, wqkv_fp8, q_norm_w, k_norm_w, wo_fp8, post_norm_w, w_gate_up_fp8,
+                                  w_down_fp8);
+    if (rc) return rc;
+    LayerW &L = m->layers[layer];
+    L.s_qkv = wqkv_scales; L.s_o = wo_scales; L.s_gu = w_gate_up_scales; L.s_down = w_down_scales;
     return QTTS_OK;
 }
 
@@ -2238,10 +2276,10 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         char *vc = m->kv + ((size_t)m->n_layers + l) * layer_kv;
         if (split_norm) {
             if ((rc = qtts_rmsnorm(cur, H, L.in_norm, m->eps, xn, H, N, H, stream))) return rc;
-            if ((rc = qtts_linear_fused(xn, H, nullptr, 0, L.wqkv, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, 0,
-                                        qkv, qkvw, N, qkvw, H, stream))) return rc;
-        } else if ((rc = qtts_linear_fused(cur, H, nullptr, 0, L.wqkv, nullptr, nullptr, 0, L.in_norm, m->eps, nullptr, 0, 0,
-                                           qkv, qkvw, N, qkvw, H, stream))) return rc;
+            if ((rc = stack_linear(xn, H, L.wqkv, L.s_qkv, nullptr, 0, nullptr, 0.f, qkv, qkvw, N, qkvw, H, nullptr, 0, stream)))
+                return rc;
+        } else if ((rc = stack_linear(cur, H, L.wqkv, L.s_qkv, nullptr, 0, L.in_norm, m->eps, qkv, qkvw, N, qkvw, H, nullptr, 0,
+                                      stream))) return rc;
         if (decode) {
             if ((rc = attention_decode_fused_impl(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
                                                   positions, slot_mapping, kc, vc, block_tables, max_blocks,
@@ -2253,19 +2291,14 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
             if ((rc = qtts_paged_attention(qkv, qkvw, kc, vc, block_tables, max_blocks, row_seq, context_lens,
                                            max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws, stream))) return rc;
         }
-        if ((rc = qtts_linear_fused(attn, Hq * 128, nullptr, 0, L.wo, nullptr, cur, H, nullptr, 0.f, nullptr, 0, 0, xa, H,
-                                    N, H, Hq * 128, stream))) return rc;
+        if ((rc = stack_linear(attn, Hq * 128, L.wo, L.s_o, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, nullptr, 0, stream)))
+            return rc;
         if (split_norm) {
             if ((rc = qtts_rmsnorm(xa, H, L.post_norm, m->eps, xn, H, N, H, stream))) return rc;
-            if ((rc = qtts_linear_swiglu(xn, H, L.wgu, nullptr, 0.f, act, m->inter, N, m->inter, H, stream))) return rc;
-        } else if ((rc = qtts_linear_swiglu(xa, H, L.wgu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
-        {
-            LinArgs a;
-            a.x = act; a.ldx = m->inter; a.ids = nullptr; a.id_rows = 0; a.wp = (const uint4 *)L.wdown; a.bias = nullptr;
-            a.res = xa; a.ldr = H; a.nw = nullptr; a.eps = 0.f; a.xnorm_out = nullptr; a.ldxn = 0; a.out = xb; a.ldo = H;
-            a.M = N; a.N = H; a.K = m->inter; a.tiles_per_wg = 1;
-            if ((rc = launch_linear2(a, 0, (hipStream_t)stream, false, (float *)(m->ws + W.parts), W.parts_bytes))) return rc;
-        }
+            if ((rc = stack_swiglu(xn, H, L.wgu, L.s_gu, nullptr, 0.f, act, m->inter, N, m->inter, H, stream))) return rc;
+        } else if ((rc = stack_swiglu(xa, H, L.wgu, L.s_gu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
+        if ((rc = stack_linear(act, m->inter, L.wdown, L.s_down, xa, H, nullptr, 0.f, xb, H, N, H, m->inter,
+                               (float *)(m->ws + W.parts), W.parts_bytes, stream))) return rc;
         // Fixed roles: xa = post-attention residual stream, xb = layer output.  The next layer reads xb
         // (qkv GEMM, o_proj residual) before its down_proj overwrites it, all stream-ordered.
         cur = xb;

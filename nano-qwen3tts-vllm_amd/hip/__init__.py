@@ -57,6 +57,7 @@ _SIGS = {
     "qtts_advance_decode": (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _i, _p]),
     "qtts_model_create": (_p, [_i, _i, _i, _i, _i, _i, _f]),
     "qtts_model_destroy": (None, [_p]),
+    "qtts_model_set_layer_fp8": (_i, [_p, _i] + [_p] * 12),
     "qtts_model_set_layer": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "qtts_model_set_final_norm": (_i, [_p, _p]),
     "qtts_model_set_rope": (_i, [_p, _p, _p, _i]),

@@ -8,6 +8,7 @@ P/engine/model_runner/base.py:131-164.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -47,7 +48,13 @@ def rope_tables(head_dim: int, theta: float, max_pos: int):
 
 class HipDecoder:
     def __init__(self, weights: dict, shape: DecoderShape, num_kv_blocks: int, max_rows: int,
-                 max_context: int = 1024, device="cuda", max_pos: int = 2048, prefix: str = "model."):
+                 max_context: int = 1024, device="cuda", max_pos: int = 2048, prefix: str = "model.",
+                 weight_dtype: str | None = None):
+        """weight_dtype "bf16" (the reference's) or "fp8": the four GEMM weights of every layer as e4m3 with a
+        power-of-two scale per row (an extension; default from QTTS_WEIGHT_DTYPE, else bf16)."""
+        self.weight_dtype = weight_dtype or os.environ.get("QTTS_WEIGHT_DTYPE", "bf16")
+        assert self.weight_dtype in ("bf16", "fp8"), self.weight_dtype
+        fp8 = self.weight_dtype == "fp8"
         self.shape = s = shape
         self.device = torch.device(device)
         self.max_rows, self.max_context, self.max_pos = max_rows, max_context, max_pos
@@ -68,18 +75,32 @@ class HipDecoder:
             p = f"{prefix}layers.{i}."
             wqkv = torch.cat([weights[p + "self_attn.q_proj.weight"], weights[p + "self_attn.k_proj.weight"],
                               weights[p + "self_attn.v_proj.weight"]], 0)
-            wqkv_p = hip.pack_weight(dev(wqkv))
-            wo_p = hip.pack_weight(dev(weights[p + "self_attn.o_proj.weight"]))
-            wgu_p = hip.pack_gate_up(dev(weights[p + "mlp.gate_proj.weight"]), dev(weights[p + "mlp.up_proj.weight"]))
-            wd_p = hip.pack_weight(dev(weights[p + "mlp.down_proj.weight"]))
+            if fp8:
+                wqkv_p, s_qkv = hip.pack_weight_fp8(dev(wqkv))
+                wo_p, s_o = hip.pack_weight_fp8(dev(weights[p + "self_attn.o_proj.weight"]))
+                wgu_p, s_gu = hip.pack_gate_up_fp8(dev(weights[p + "mlp.gate_proj.weight"]), dev(weights[p + "mlp.up_proj.weight"]))
+                wd_p, s_d = hip.pack_weight_fp8(dev(weights[p + "mlp.down_proj.weight"]))
+            else:
+                wqkv_p = hip.pack_weight(dev(wqkv))
+                wo_p = hip.pack_weight(dev(weights[p + "self_attn.o_proj.weight"]))
+                wgu_p = hip.pack_gate_up(dev(weights[p + "mlp.gate_proj.weight"]), dev(weights[p + "mlp.up_proj.weight"]))
+                wd_p = hip.pack_weight(dev(weights[p + "mlp.down_proj.weight"]))
             torch.cuda.synchronize()
             del self._keep[-5:]          # row-major copies are no longer needed once packed
-            tensors = [dev(weights[p + "input_layernorm.weight"]), wqkv_p, dev(weights[p + "self_attn.q_norm.weight"]),
-                       dev(weights[p + "self_attn.k_norm.weight"]), wo_p, dev(weights[p + "post_attention_layernorm.weight"]),
-                       wgu_p, wd_p]
+            norms = [dev(weights[p + "input_layernorm.weight"]), dev(weights[p + "self_attn.q_norm.weight"]),
+                     dev(weights[p + "self_attn.k_norm.weight"]), dev(weights[p + "post_attention_layernorm.weight"])]
             self._keep += [wqkv_p, wo_p, wgu_p, wd_p]
             self.packed_gate_up = getattr(self, "packed_gate_up", []) + [wgu_p]
-            hip.check(hip.lib.qtts_model_set_layer(h, i, *[hip.ptr(t) for t in tensors]), "model_set_layer")
+            P = hip.ptr
+            if fp8:
+                self._keep += [s_qkv, s_o, s_gu, s_d]
+                self.gate_up_scales = getattr(self, "gate_up_scales", []) + [s_gu]
+                hip.check(hip.lib.qtts_model_set_layer_fp8(h, i, P(norms[0]), P(wqkv_p), P(s_qkv), P(norms[1]), P(norms[2]),
+                                                           P(wo_p), P(s_o), P(norms[3]), P(wgu_p), P(s_gu), P(wd_p), P(s_d)),
+                          "model_set_layer_fp8")
+            else:
+                hip.check(hip.lib.qtts_model_set_layer(h, i, P(norms[0]), P(wqkv_p), P(norms[1]), P(norms[2]), P(wo_p),
+                                                       P(norms[3]), P(wgu_p), P(wd_p)), "model_set_layer")
         self.final_norm = dev(weights[prefix + "norm.weight"])
         hip.check(hip.lib.qtts_model_set_final_norm(h, hip.ptr(self.final_norm)), "set_final_norm")
         cos, sin = rope_tables(s.head_dim, s.rope_theta, max_pos)
