@@ -38,6 +38,24 @@ static thread_local char g_err[512] = "";
 #define QLAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
     snprintf(g_err, sizeof(g_err), "%s: %s", __func__, hipGetErrorString(e_)); return (int)e_; } } while (0)
 
+// Kernels that ask for more dynamic LDS than the default limit: the limit is raised once per (kernel, device).
+// Returns false (with the error text set) when the device refuses.
+static bool allow_dynamic_lds(const void *kernel, size_t bytes) {
+    struct Seen { const void *k; int dev; };
+    static thread_local std::vector<Seen> seen;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    for (const Seen &e : seen)
+        if (e.k == kernel && e.dev == dev) return true;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "cannot raise the dynamic LDS limit to %zu bytes: %s", bytes, hipGetErrorString(e));
+        return false;
+    }
+    seen.push_back({kernel, dev});
+    return true;
+}
+
 extern "C" int qtts_version(void) { return 100; }
 extern "C" const char *qtts_last_error(void) { return g_err; }
 
@@ -719,25 +737,16 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
 }
 
 template <int KSW, int TM, int EPI>
-static void launch_rows_inst(dim3 grid, hipStream_t s, const LinArgs &a, int tpw, const RowsArgs &r) {
+static bool launch_rows_inst(dim3 grid, hipStream_t s, const LinArgs &a, int tpw, const RowsArgs &r) {
     const size_t shmem = (size_t)2 * 8 * TM * 64 * sizeof(float4_t);
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_rows_kernel<KSW, TM, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        once = true;
-    }
     if (a.wscale) {
-        static bool once8 = false;
-        if (!once8) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_rows_kernel<KSW, TM, EPI, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            once8 = true;
-        }
+        if (!allow_dynamic_lds(reinterpret_cast<const void *>(&linear_rows_kernel<KSW, TM, EPI, true>), shmem)) return false;
         hipLaunchKernelGGL((linear_rows_kernel<KSW, TM, EPI, true>), grid, dim3(512), shmem, s, a.x, a.wp, a.ldx, a.N, a.M, tpw, r);
-        return;
+        return true;
     }
+    if (!allow_dynamic_lds(reinterpret_cast<const void *>(&linear_rows_kernel<KSW, TM, EPI>), shmem)) return false;
     hipLaunchKernelGGL((linear_rows_kernel<KSW, TM, EPI>), grid, dim3(512), shmem, s, a.x, a.wp, a.ldx, a.N, a.M, tpw, r);
+    return true;
 }
 
 // Bytes of fp32 scratch the K-split form of a prompt GEMM needs (0 when the GEMM runs in one part).
@@ -777,7 +786,8 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     const int gx = (ntiles + tpw - 1) / tpw;
     dim3 grid(((gx + 7) / 8) * 8 * r.rgroups, kparts);
     const int epi = kparts > 1 ? 2 : (silu_pairs ? 1 : 0);
-#define QR(KSW_, TM_, EPI_) launch_rows_inst<KSW_, TM_, EPI_>(grid, s, a, tpw, r)
+    bool ok = true;
+#define QR(KSW_, TM_, EPI_) ok = launch_rows_inst<KSW_, TM_, EPI_>(grid, s, a, tpw, r)
     if (ksw == 12) QR(12, 2, 0);
     else if (ksw == 8) {
         if (TM == 2) { if (epi == 0) QR(8, 2, 0); else if (epi == 1) QR(8, 2, 1); else QR(8, 2, 2); }
@@ -787,6 +797,7 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
         else { if (epi == 0) QR(4, 4, 0); else QR(4, 4, 1); }
     }
 #undef QR
+    if (!ok) return false;                               // (the caller's single-tile path still works)
     if (kparts > 1) {
         const long quads = (long)a.M * (a.N / 4);
         hipLaunchKernelGGL(linear_parts_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, scratch, kparts, a.M,
@@ -1424,27 +1435,17 @@ extern "C" int qtts_paged_attention(const void *q, int ldq, const void *k_cache,
         // per-row kernel is faster (a 48-token prompt: 6.6 against 10 us per layer; 200 tokens: 25 against 14 us)
         const dim3 grid((N + 15) / 16, Hkv);
         const size_t shmem = (size_t)PA_NTG * G * PA_WAVE_LDS;
-        if (G == 1) {
-            static bool once1 = false;
-            if (!once1) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_attn_mfma_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-                once1 = true;
-            }
+        const void *kern = G == 1 ? reinterpret_cast<const void *>(&prefill_attn_mfma_kernel<1>)
+                                  : reinterpret_cast<const void *>(&prefill_attn_mfma_kernel<2>);
+        if (!allow_dynamic_lds(kern, shmem)) return QTTS_ESTATE;
+        if (G == 1)
             hipLaunchKernelGGL((prefill_attn_mfma_kernel<1>), grid, dim3(64 * PA_NTG), shmem, s, (const bf16_t *)q, ldq,
                                (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq,
                                context_lens, scale, (bf16_t *)out, ldo, N, Hkv);
-        } else {
-            static bool once = false;
-            if (!once) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_attn_mfma_kernel<2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-                once = true;
-            }
+        else
             hipLaunchKernelGGL((prefill_attn_mfma_kernel<2>), grid, dim3(128 * PA_NTG), shmem, s, (const bf16_t *)q, ldq,
                                (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq,
                                context_lens, scale, (bf16_t *)out, ldo, N, Hkv);
-        }
         QLAUNCH();
         return QTTS_OK;
     }
@@ -1844,87 +1845,136 @@ __device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t offset, uin
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
-// One workgroup per row; V <= 4096 values staged in LDS.
+// Order-preserving map float -> uint32 (larger float <-> larger key) and back.
+__device__ __forceinline__ uint32_t fkey(float v) {
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// Inclusive prefix sums over the 256 threads of a workgroup (thread order); sm: 4 words of LDS scratch.
+template <typename T>
+__device__ __forceinline__ T block_scan256(T v, T *sm) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) sm[w] = x;
+    __syncthreads();
+    T off = 0;
+    for (int i = 0; i < w; ++i) off += sm[i];
+    __syncthreads();
+    return x + off;
+}
+
+// One workgroup per row; V <= 4096 values staged in LDS.  Greedy rows: argmax, lowest index on ties.  Sampling rows
+// (P/layers/sampler.py:15-24: logits / T, everything below the k-th largest value removed, softmax, one draw):
+// the k-th largest value by a 4-pass radix select over the order-preserving keys (a 256-bin histogram per byte),
+// then the inverse CDF in index order with a chunk of consecutive indices per thread and a workgroup prefix sum.
 __global__ __launch_bounds__(256) void sample_topk_kernel(const bf16_t *__restrict__ logits, int ld,
                                                           const float *__restrict__ temps, int top_k, uint64_t seed,
                                                           uint64_t offset, const uint64_t *__restrict__ offset_dev,
                                                           const uint8_t *__restrict__ greedy, int64_t *__restrict__ out,
                                                           int ldout, int V) {
     __shared__ float val[4096];
+    __shared__ int hist[256];
     __shared__ float wv[4];
     __shared__ int wi[4];
-    __shared__ float kth_s;
+    __shared__ int sel[2];
+    __shared__ float fs[4];
+    __shared__ int picked;
     const int row = blockIdx.x;
     const bool is_greedy = greedy && greedy[row];
     const float T = is_greedy ? 1.0f : temps[row];
-    if (is_greedy) top_k = 1;            // round 0 below is exactly argmax with the lowest index on ties
     if (offset_dev) offset += *offset_dev;
-    for (int i = threadIdx.x; i < V; i += 256) val[i] = bf2f(logits[(size_t)row * ld + i]) / T;
-    __syncthreads();
-    // k-th largest by k rounds of "largest value strictly below the previous one / next duplicate".
-    // Values are compared with (value, index) order so duplicates are counted one by one.
-    float prev_v = INFINITY;
-    int prev_i = -1;
-    float maxv = -INFINITY;
-    for (int k = 0; k < top_k; ++k) {
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int i = threadIdx.x; i < V; i += 256) {
-            float v = val[i];
-            bool after_prev = (v < prev_v) || (v == prev_v && i > prev_i);
-            if (after_prev && (v > best || (v == best && i < bi))) {
-                best = v;
-                bi = i;
-            }
+    // maximum (and its lowest index) while staging
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += 256) {
+        const float v = bf2f(logits[(size_t)row * ld + i]) / T;
+        val[i] = v;
+        if (v > best) {               // ascending i per thread: the first maximum is kept
+            best = v;
+            bi = i;
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            float ov = __shfl_xor(best, o);
-            int oi = __shfl_xor(bi, o);
-            if (ov > best || (ov == best && oi < bi)) {
-                best = ov;
-                bi = oi;
-            }
-        }
-        if ((threadIdx.x & 63) == 0) {
-            wv[threadIdx.x >> 6] = best;
-            wi[threadIdx.x >> 6] = bi;
-        }
-        __syncthreads();
-        best = wv[0];
-        bi = wi[0];
-        for (int w = 1; w < 4; ++w)
-            if (wv[w] > best || (wv[w] == best && wi[w] < bi)) {
-                best = wv[w];
-                bi = wi[w];
-            }
-        __syncthreads();
-        prev_v = best;
-        prev_i = bi;
-        if (k == 0) maxv = best;
     }
-    if (is_greedy) {
-        if (threadIdx.x == 0) out[(size_t)row * ldout] = prev_i;
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        wv[threadIdx.x >> 6] = best;
+        wi[threadIdx.x >> 6] = bi;
+    }
+    if (threadIdx.x == 0) picked = -1;
+    __syncthreads();
+    best = wv[0];
+    bi = wi[0];
+    for (int w = 1; w < 4; ++w)
+        if (wv[w] > best || (wv[w] == best && wi[w] < bi)) {
+            best = wv[w];
+            bi = wi[w];
+        }
+    if (is_greedy || top_k <= 1) {
+        if (threadIdx.x == 0) out[(size_t)row * ldout] = bi;
         return;
     }
-    const float kth = prev_v;
-    // softmax over values >= kth (ties at the threshold are all kept, as `logits < kth` removes only smaller ones)
+    const float maxv = best;
+    // ---- k-th largest value
+    uint32_t prefix = 0, mask = 0;
+    int krem = top_k;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < V; i += 256) {
+            const uint32_t key = fkey(val[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+        }
+        __syncthreads();
+        const int c = hist[255 - threadIdx.x];                   // thread t looks at bin 255 - t: counts from the top
+        const int incl = block_scan256<int>(c, wi);
+        if (incl >= krem && incl - c < krem) {                    // exactly one thread
+            sel[0] = 255 - threadIdx.x;
+            sel[1] = krem - (incl - c);
+        }
+        __syncthreads();
+        prefix |= (uint32_t)sel[0] << shift;
+        mask |= 0xffu << shift;
+        krem = sel[1];
+        __syncthreads();
+    }
+    const float kth = fkey_inv(prefix);
+    // ---- softmax weights over values >= kth (ties at the threshold all stay, as `logits < kth` removes only smaller
+    // ones), a chunk of consecutive indices per thread
+    const int C = (V + 255) >> 8;
+    const int i0 = threadIdx.x * C, i1 = min(i0 + C, V);
     float part = 0.f;
-    for (int i = threadIdx.x; i < V; i += 256) {
-        float v = val[i];
-        float p = (v >= kth) ? __expf(v - maxv) : 0.f;
+    for (int i = i0; i < i1; ++i) {
+        const float v = val[i];
+        const float p = (v >= kth) ? __expf(v - maxv) : 0.f;
         val[i] = p;
         part += p;
     }
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    if ((threadIdx.x & 63) == 0) wv[threadIdx.x >> 6] = part;
+    const float incl = block_scan256<float>(part, fs);
+    if (threadIdx.x == 255) wv[0] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float total = wv[0] + wv[1] + wv[2] + wv[3];
-        const float u = rng_uniform(seed, offset, row) * total;
-        float c = 0.f;
-        int pick = -1, lastnz = 0;
-        for (int i = 0; i < V; ++i) {
-            float p = val[i];
+    const float total = wv[0];
+    const float u = rng_uniform(seed, offset, row) * total;
+    const float excl = incl - part;
+    if (part > 0.f && u >= excl && u < incl) {
+        float c = excl;
+        int pick = -1, lastnz = i0;
+        for (int i = i0; i < i1; ++i) {
+            const float p = val[i];
             if (p > 0.f) {
                 lastnz = i;
                 c += p;
@@ -1934,8 +1984,21 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const bf16_t *__restri
                 }
             }
         }
-        out[(size_t)row * ldout] = pick >= 0 ? pick : lastnz;
+        picked = pick >= 0 ? pick : lastnz;
     }
+    __syncthreads();
+    if (picked < 0) {
+        // u fell on the total through rounding: the last index that has weight
+        int last = -1;
+        for (int i = i0; i < i1; ++i)
+            if (val[i] > 0.f) last = i;
+        for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
+        if ((threadIdx.x & 63) == 0) wi[threadIdx.x >> 6] = last;
+        __syncthreads();
+        if (threadIdx.x == 0) picked = max(max(wi[0], wi[1]), max(wi[2], wi[3]));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)row * ldout] = picked;
 }
 
 extern "C" int qtts_pick_token(const void *logits, int ld, const float *temperatures, const uint8_t *greedy_flags,

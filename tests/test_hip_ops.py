@@ -258,6 +258,30 @@ def test_sample_topk_distribution(hip):
     assert not torch.equal(other, got)
 
 
+@pytest.mark.parametrize("V,k", [(3072, 50), (2048, 50), (512, 7), (4096, 1), (100, 100)])
+def test_sample_topk_support_rows(hip, V, k):
+    """Different rows, coarse logits with many ties at the k-th value: every draw lies in the reference's support
+    (all values >= the k-th largest stay), and with several hundred draws per row every row's draws cover more than
+    one index when the support has more than one."""
+    g = torch.Generator().manual_seed(V + k)
+    rows = 24
+    base = (torch.randn(rows, V, generator=g) * 1.5).mul(4).round().div(4).bfloat16()       # quarter steps: many ties
+    temps = torch.linspace(0.6, 1.3, rows)
+    probs = O.topk_probs(base, temps, k)
+    rep = 200
+    logits = base.repeat_interleave(rep, 0).contiguous()
+    got = hip.sample_topk(logits.to(DEV), temps.repeat_interleave(rep).to(DEV), k, seed=7, offset=3).cpu().view(rows, rep)
+    for r in range(rows):
+        support = set(torch.nonzero(probs[r] > 0).flatten().tolist())
+        assert len(support) >= k
+        drawn = set(got[r].tolist())
+        assert drawn <= support, (r, sorted(drawn - support)[:5])
+        if k > 1:
+            assert len(drawn) > 1
+        else:
+            assert drawn == {int(torch.argmax(base[r].float()))}
+
+
 def test_embedding_gather(hip):
     table = torch.randn(300, 256).bfloat16()
     ids = torch.tensor([0, 299, 5, 5], dtype=torch.int64)
