@@ -66,3 +66,23 @@ def test_models_bit_exact(size, seed, tag):
     frames, margins, _ = O.frame_loop(tw, tc, pw, pc, prompts, torch.from_numpy(g["f_text_adds"]), 6)
     assert np.array_equal(frames.numpy(), g["f_frames"])
     assert np.allclose(margins.numpy(), g["f_margins"])
+
+
+def test_fp8_row_quantisation_properties():
+    """The fp8 extension's quantiser: power-of-two scales, |q| <= 448, q * scale exactly a bf16 number, zero rows
+    keep scale 1, and the error against the original stays within half an e4m3 step of the row scale."""
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(48, 256, generator=g) * 0.07).bfloat16()
+    w[2] = 0
+    w[5, 0] = 448.0 * 2.0 ** -5
+    w[5] = w[5].clamp(-14.0, 14.0)
+    q, scale, deq = O.quantize_fp8_rows(w)
+    assert torch.equal(torch.frexp(scale)[0], torch.full_like(scale, 0.5))          # powers of two
+    assert float(scale[2]) == 1.0 and float(q[2].float().abs().max()) == 0.0
+    assert float(q.float().abs().max()) <= 448.0
+    assert float(scale[5]) == 2.0 ** -5 and float(q[5, 0].float()) == 448.0
+    assert torch.equal(deq.float(), q.float() * scale[:, None])
+    amax = w.float().abs().amax(1)
+    assert bool(((amax / scale <= 448.0) & ((amax / scale > 224.0) | (amax == 0))).all())
+    err = (deq.float() - w.float()).abs()
+    assert bool((err <= w.float().abs() * 2.0 ** -4 + scale[:, None] * 2.0 ** -10).all())
