@@ -76,7 +76,10 @@ class FrameEngine:
         self.ptab_ptrs = torch.tensor([t.data_ptr() for t in self.pr.tables], dtype=torch.int64, device=dev)
         self.rows: list[Stream | None] = [None] * max_streams
         self.streams: dict[str, Stream] = {}
-        self.graphs: dict[tuple, hip.Graph] = {}
+        self.graphs: dict[tuple, hip.Graph] = {}            # talker part, per (batch bucket, context bucket)
+        self.code_graphs: dict[int, hip.Graph] = {}          # predictor burst + glue, per batch bucket
+        self._codes_host = torch.zeros(max_streams, 16, dtype=torch.int64).pin_memory()
+        self._codes_event = torch.cuda.Event()
         self._pred_meta_bs = None
         self._next_sid = 0
         self.stream = self.tr.stream
@@ -190,6 +193,12 @@ class FrameEngine:
         self._pred_meta_bs = bs
 
     def _frame_body(self, bs: int, max_context: int):
+        """One whole frame: the 16 codes of this frame, then the talker step that starts the next one."""
+        self._codes_part(bs)
+        self._talker_part(bs, max_context)
+
+    def _codes_part(self, bs: int):
+        """Predictor input, 15-step burst, glue: after this the frame's 16 codes (and the next talker input) exist."""
         tr, pr, lib, s = self.tr, self.pr, hip.lib, hip.stream
         H = self.H
         hip.check(lib.qtts_predictor_input(hip.ptr(self.cur_hidden), hip.ptr(tr.codec_embedding), hip.ptr(self.cur_token),
@@ -201,6 +210,10 @@ class FrameEngine:
                                       hip.ptr(pr.burst_tokens), bs, hip.ptr(self.text_add),
                                       self.max_text_frames * H, hip.ptr(self.frame_idx), hip.ptr(self.next_x),
                                       hip.ptr(self.codes), bs, H, tr.vocab, pr.vocab, s()), "frame_glue")
+
+    def _talker_part(self, bs: int, max_context: int):
+        """Metadata advance, talker decode step + codec head, pick: hidden state and first code of the next frame."""
+        tr, lib, s = self.tr, hip.lib, hip.stream
         st, mb = tr.dstage, tr.max_blocks_per_seq
         hip.check(lib.qtts_advance_decode(hip.ptr(st.d("positions")), hip.ptr(st.d("slots")), hip.ptr(st.d("ctx")),
                                           hip.ptr(st.d("tables")), mb, hip.ptr(self.frame_idx), hip.ptr(self.rng),
@@ -217,31 +230,44 @@ class FrameEngine:
         mx = min(mx + 1, self.tr.config.max_model_len)
         return min(((mx + 127) // 128) * 128, self.tr.config.max_model_len)
 
-    def _launch_frame(self, bs, max_ctx):
+    def _launch_codes(self, bs):
         if self.enforce_eager:
             self.pr.prepare_resident(bs)
-            self._frame_body(bs, max_ctx)
+            self._codes_part(bs)
+            return
+        g = self.code_graphs.get(bs)
+        if g is None:
+            self.pr.prepare_resident(bs)          # uploads a stage table: not allowed while capturing
+            g = self.code_graphs[bs] = hip.Graph.capture(lambda: self._codes_part(bs))
+        g.launch()
+
+    def _launch_talker(self, bs, max_ctx):
+        if self.enforce_eager:
+            self._talker_part(bs, max_ctx)
             return
         key = (bs, max_ctx)
         g = self.graphs.get(key)
         if g is None:
-            self.pr.prepare_resident(bs)          # uploads a stage table: not allowed while capturing
-            g = self.graphs[key] = hip.Graph.capture(lambda: self._frame_body(bs, max_ctx))
+            g = self.graphs[key] = hip.Graph.capture(lambda: self._talker_part(bs, max_ctx))
         g.launch()
 
     def capture_all(self, max_context: int | None = None) -> int:
-        """Captures the frame graph of every (batch bucket, context bucket) this engine can meet, so that no
-        capture happens while streams are being served (the reference captures its decode graphs at start-up
-        too, P/engine/model_runner/talker_mode_runner.py:157-192).  Returns the number of graphs held."""
+        """Captures the graphs of every (batch bucket, context bucket) this engine can meet — one codes graph per
+        batch bucket, one talker graph per (batch, context) bucket — so that no capture happens while streams are
+        being served (the reference captures its decode graphs at start-up too,
+        P/engine/model_runner/talker_mode_runner.py:157-192).  Returns the number of talker graphs held."""
         if self.enforce_eager:
             return 0
         top = min(max_context or self.tr.config.max_model_len, self.tr.config.max_model_len)
         with self.tr.on_stream():
             for bs in (b for b in self.tr.graph_bs if b <= self._bucket_for(self.max_streams)):
                 self.pr.prepare_resident(bs)
+                self._setup_predictor_meta(bs)
+                if bs not in self.code_graphs:
+                    self.code_graphs[bs] = hip.Graph.capture(lambda: self._codes_part(bs))
                 for ctx in range(128, top + 1, 128):
                     if (bs, ctx) not in self.graphs:
-                        self.graphs[(bs, ctx)] = hip.Graph.capture(lambda: self._frame_body(bs, ctx))
+                        self.graphs[(bs, ctx)] = hip.Graph.capture(lambda: self._talker_part(bs, ctx))
             self.tr.stream.synchronize()
         return len(self.graphs)
 
@@ -256,8 +282,9 @@ class FrameEngine:
         with self.tr.on_stream():
             self._setup_predictor_meta(bs)
             for f in range(n):
-                self._launch_frame(bs, self._max_ctx_bucket(extra_frames=f + 1))
+                self._launch_codes(bs)
                 out[f].copy_(self.codes[:bs], non_blocking=True)
+                self._launch_talker(bs, self._max_ctx_bucket(extra_frames=f + 1))
             self.tr.stream.synchronize()
         for s in self.rows:
             if s is not None:
@@ -272,8 +299,15 @@ class FrameEngine:
         bs = self._bucket()
         with self.tr.on_stream():
             self._setup_predictor_meta(bs)
-            self._launch_frame(bs, self._max_ctx_bucket())
-            codes = self.codes[:bs].tolist()
+            # the frame's codes are final once the predictor burst is done: they travel to the host while the talker
+            # step that starts the next frame is already running (the reference yields before that step too,
+            # P/interface.py:1241-1290)
+            self._launch_codes(bs)
+            self._codes_host[:bs].copy_(self.codes[:bs], non_blocking=True)
+            self._codes_event.record(torch.cuda.current_stream())
+            self._launch_talker(bs, self._max_ctx_bucket())
+            self._codes_event.synchronize()
+            codes = self._codes_host[:bs].tolist()
         res = {}
         for s in list(self.streams.values()):
             c = codes[s.row]
@@ -287,5 +321,6 @@ class FrameEngine:
 
     def exit(self):
         self.graphs.clear()
+        self.code_graphs.clear()
         self.talker.exit()
         self.pred.exit()
