@@ -235,6 +235,7 @@ struct LinArgs {
     bf16_t *xnorm_out; int ldxn;
     bf16_t *out; int ldo;
     int M, N, K, tiles_per_wg;
+    const bf16_t *next_nw = nullptr; bf16_t *next_xn = nullptr; int ldnn = 0;   // K-split prompt GEMM only: also RMSNorm(out) * next_nw
     const float *wscale = nullptr;   // non-null: wp holds fp8 (e4m3) weights, two k-steps per 16-byte fragment; scale per packed row
     int dbg;      // bit0: tuning experiment (every tile reads weight tile 0); bits 8+: row-tile count of a prefill launch
 };
@@ -714,6 +715,54 @@ __global__ __launch_bounds__(256) void linear_parts_kernel(const float *part, in
     *reinterpret_cast<uint2 *>(out + (size_t)m * ldo + n) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
 }
 
+// The same, one workgroup per row, followed by the RMSNorm of the finished row with the weight of the layer that
+// consumes it (the arithmetic and summation order of rmsnorm_kernel): saves the norm's own launch.  N % 8 == 0.
+__global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *part, int kparts, int mpad, int N,
+                                                                const bf16_t *bias, const bf16_t *res, int ldr, bf16_t *out,
+                                                                int ldo, const bf16_t *nw, float eps, bf16_t *xn, int ldxn) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    bf16_t *orow = out + (size_t)m * ldo;
+    float ss = 0.f;
+    for (int n = threadIdx.x * 8; n < N; n += 256 * 8) {
+        float q[8];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            float4_t sum = *reinterpret_cast<const float4_t *>(part + (size_t)m * N + n + 4 * hlf);
+            for (int k = 1; k < kparts; ++k) sum += *reinterpret_cast<const float4_t *>(part + ((size_t)k * mpad + m) * N + n + 4 * hlf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[4 * hlf + j] = sum[j];
+        }
+        Frag rf, bfv, o;
+        rf.u = res ? *reinterpret_cast<const uint4 *>(res + (size_t)m * ldr + n) : make_uint4(0, 0, 0, 0);
+        bfv.u = bias ? *reinterpret_cast<const uint4 *>(bias + n) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = q[j];
+            if (bias) v += bf2f(bfv.h[j]);
+            v = rbf(v);
+            if (res) v = v + bf2f(rf.h[j]);
+            o.h[j] = f2bf(v);
+            const float r = bf2f(o.h[j]);
+            ss += r * r;
+        }
+        *reinterpret_cast<uint4 *>(orow + n) = o.u;
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float rstd = 1.0f / sqrtf(tot / (float)N + eps);
+    for (int n = threadIdx.x * 8; n < N; n += 256 * 8) {
+        Frag f, wv, o;
+        f.u = *reinterpret_cast<const uint4 *>(orow + n);          // this thread's own stores
+        wv.u = *reinterpret_cast<const uint4 *>(nw + n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.h[j] = f2bf(rbf(bf2f(f.h[j]) * rstd) * bf2f(wv.h[j]));
+        *reinterpret_cast<uint4 *>(xn + (size_t)m * ldxn + n) = o.u;
+    }
+}
+
 template <int KSW, int PRO, bool DB, int EPI, bool SUB = false>
 static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs &a) {
     size_t shmem = (size_t)2 * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
@@ -754,6 +803,12 @@ static size_t linear_rows_scratch_bytes(int M, int N, int K) {
     const int KS = K / 32;
     if (M <= 16 || KS % 8 != 0 || KS / 8 <= 12) return 0;
     return (size_t)(KS / 64) * M * N * sizeof(float);
+}
+
+// True when launch_linear_rows runs this shape as K parts (and can therefore take the fused norm of the result).
+static bool linear_rows_is_ksplit(int M, int N, int K, size_t scratch_bytes) {
+    const size_t need = linear_rows_scratch_bytes(M, N, K);
+    return need > 0 && scratch_bytes >= need && (K / 32) % 64 == 0 && N % 8 == 0 && !(g_dbg_linear & (2 | 32));   // bit 5: tests switch the fusion off
 }
 
 // Prompt GEMM (more than one 16-row tile, plain activations).  Returns false when the shape is not covered and the
@@ -800,8 +855,12 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     if (!ok) return false;                               // (the caller's single-tile path still works)
     if (kparts > 1) {
         const long quads = (long)a.M * (a.N / 4);
-        hipLaunchKernelGGL(linear_parts_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, scratch, kparts, a.M,
-                           a.M, a.N, a.bias, a.res, a.ldr, a.out, a.ldo);
+        if (a.next_nw)
+            hipLaunchKernelGGL(linear_parts_norm_kernel, dim3(a.M), dim3(256), 0, s, scratch, kparts, a.M, a.N, a.bias, a.res,
+                               a.ldr, a.out, a.ldo, a.next_nw, a.eps, a.next_xn, a.ldnn);
+        else
+            hipLaunchKernelGGL(linear_parts_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, scratch, kparts, a.M,
+                               a.M, a.N, a.bias, a.res, a.ldr, a.out, a.ldo);
     }
     return true;
 }
@@ -822,6 +881,7 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
         QLAUNCH();
         return QTTS_OK;
     }
+    QCHECK(!a.next_nw, "linear: the fused norm of the result exists for the K-split prompt GEMM only");
     const int KS = a.K / 32;
     static const int ksws[] = {1, 2, 4, 6, 8, 12, 24};
     int KSW = 0;
@@ -2147,8 +2207,10 @@ struct LayerW {
 // The decoder stack's GEMMs with bf16 or fp8 weights (wscale != null).
 static int stack_linear(const void *x, int ldx, const void *w, const float *wscale, const void *residual, int ldr,
                         const void *norm_w, float eps, void *out, int ldo, int M, int N, int K, float *scratch,
-                        size_t scratch_bytes, qtts_stream_t stream) {
+                        size_t scratch_bytes, qtts_stream_t stream, const void *next_norm_w = nullptr,
+                        void *next_xn = nullptr, int ldnn = 0) {
     LinArgs a;
+    a.next_nw = (const bf16_t *)next_norm_w; a.next_xn = (bf16_t *)next_xn; a.ldnn = ldnn;
     a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0; a.wp = (const uint4 *)w; a.wscale = wscale;
     a.bias = nullptr; a.res = (const bf16_t *)residual; a.ldr = ldr; a.nw = (const bf16_t *)norm_w; a.eps = eps;
     a.xnorm_out = nullptr; a.ldxn = 0; a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.tiles_per_wg = 1;
@@ -2333,12 +2395,14 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     const bf16_t *cur = (const bf16_t *)x;
     int rc;
     const bool decode = row_seq == nullptr;           // one row per sequence: fused norm/RoPE/store/attention
+    bool xn_ready = false, final_ready = false;       // a norm already applied by the producing launch
     for (int l = 0; l < m->n_layers; ++l) {
         const LayerW &L = m->layers[l];
         char *kc = m->kv + (size_t)l * layer_kv;
         char *vc = m->kv + ((size_t)m->n_layers + l) * layer_kv;
         if (split_norm) {
-            if ((rc = qtts_rmsnorm(cur, H, L.in_norm, m->eps, xn, H, N, H, stream))) return rc;
+            if (!xn_ready && (rc = qtts_rmsnorm(cur, H, L.in_norm, m->eps, xn, H, N, H, stream))) return rc;
+            xn_ready = false;
             if ((rc = stack_linear(xn, H, L.wqkv, L.s_qkv, nullptr, 0, nullptr, 0.f, qkv, qkvw, N, qkvw, H, nullptr, 0, stream)))
                 return rc;
         } else if ((rc = stack_linear(cur, H, L.wqkv, L.s_qkv, nullptr, 0, L.in_norm, m->eps, qkv, qkvw, N, qkvw, H, nullptr, 0,
@@ -2360,15 +2424,22 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
             if ((rc = qtts_rmsnorm(xa, H, L.post_norm, m->eps, xn, H, N, H, stream))) return rc;
             if ((rc = stack_swiglu(xn, H, L.wgu, L.s_gu, nullptr, 0.f, act, m->inter, N, m->inter, H, stream))) return rc;
         } else if ((rc = stack_swiglu(xa, H, L.wgu, L.s_gu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
-        if ((rc = stack_linear(act, m->inter, L.wdown, L.s_down, xa, H, nullptr, 0.f, xb, H, N, H, m->inter,
-                               (float *)(m->ws + W.parts), W.parts_bytes, stream))) return rc;
+        // a prompt's K-split down_proj also normalises the finished rows for whoever reads them next: the next
+        // layer's input norm, or the final norm (the returned hidden state)
+        const bool last = l + 1 == m->n_layers;
+        const bool fuse_next = split_norm && linear_rows_is_ksplit(N, H, m->inter, W.parts_bytes);
+        if ((rc = stack_linear(act, m->inter, L.wdown, L.s_down, xa, H, nullptr, fuse_next ? m->eps : 0.f, xb, H, N, H, m->inter,
+                               (float *)(m->ws + W.parts), W.parts_bytes, stream,
+                               fuse_next ? (last ? m->final_norm : m->layers[l + 1].in_norm) : nullptr,
+                               fuse_next ? (last ? (bf16_t *)hidden_out : xn) : nullptr, H))) return rc;
+        if (fuse_next) (last ? final_ready : xn_ready) = true;
         // Fixed roles: xa = post-attention residual stream, xb = layer output.  The next layer reads xb
         // (qkv GEMM, o_proj residual) before its down_proj overwrites it, all stream-ordered.
         cur = xb;
     }
     if (head_w) {
         if (split_norm) {
-            if ((rc = qtts_rmsnorm(cur, H, m->final_norm, m->eps, hidden_out, H, N, H, stream))) return rc;
+            if (!final_ready && (rc = qtts_rmsnorm(cur, H, m->final_norm, m->eps, hidden_out, H, N, H, stream))) return rc;
             return qtts_linear_fused(hidden_out, H, nullptr, 0, head_w, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, 0,
                                      logits_out, vocab, N, vocab, H, stream);
         }
@@ -2377,7 +2448,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
                                     logits_out, vocab, N, vocab, H, stream))) return rc;
         return QTTS_OK;
     }
-    if ((rc = qtts_rmsnorm(cur, H, m->final_norm, m->eps, hidden_out, H, N, H, stream))) return rc;
+    if (!final_ready && (rc = qtts_rmsnorm(cur, H, m->final_norm, m->eps, hidden_out, H, N, H, stream))) return rc;
     return QTTS_OK;
 }
 

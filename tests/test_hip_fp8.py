@@ -69,3 +69,34 @@ def test_fp8_stack_equals_bf16_stack_on_dequantised_weights():
     hc = c.forward(x, pos, slots, ctx, bt, L, row_seq=rs)
     err = (prompt_hidden.float() - hc.float()).abs().mean() / hc.float().abs().mean()
     assert float(err) < 0.1, float(err)
+
+
+@pytest.mark.parametrize("weight_dtype", ["bf16", "fp8"])
+def test_prompt_stack_with_fused_next_norm_equals_separate_norm(weight_dtype):
+    """A prompt through a stack whose down_proj runs K-split (intermediate size 4096): the RMSNorm of the next layer /
+    the final norm applied by the launch that finishes down_proj gives bit for bit the rows of the separate norm
+    launch, and the stack agrees with the oracle layer by layer arithmetic within the usual GEMM tolerance."""
+    from nano_qwen3tts_vllm import hip
+    from nano_qwen3tts_vllm.models.hip_decoder import DecoderShape, HipDecoder
+    shape = DecoderShape(hidden_size=512, num_layers=3, num_heads=4, num_kv_heads=2, head_dim=128, intermediate_size=4096,
+                         rope_theta=1000000.0)
+    w = _weights(shape, 33)
+    dec = HipDecoder(w, shape, num_kv_blocks=4, max_rows=256, device=DEV, weight_dtype=weight_dtype)
+    g = torch.Generator().manual_seed(8)
+    L = 70
+    x = (torch.randn(L, 512, generator=g) * 0.5).bfloat16().to(DEV)
+    pos = torch.arange(L, dtype=torch.int64, device=DEV)
+    slots = (256 + torch.arange(L, dtype=torch.int32)).to(DEV)
+    ctx = torch.arange(1, L + 1, dtype=torch.int32, device=DEV)
+    rs = torch.zeros(L, dtype=torch.int32, device=DEV)
+    bt = torch.tensor([[1, 0, 0, 0]], dtype=torch.int32, device=DEV)
+    outs = []
+    for flags in (0, 32):
+        hip.lib.qtts_debug_linear(flags)
+        try:
+            outs.append(dec.forward(x, pos, slots, ctx, bt, L, row_seq=rs).clone())
+            torch.cuda.synchronize()
+        finally:
+            hip.lib.qtts_debug_linear(0)
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[0].float().abs().mean()) > 0.1          # (not trivially zero)
