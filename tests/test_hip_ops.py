@@ -394,7 +394,8 @@ def test_attention_decode_fused(hip, Hq, Hkv, ctxs):
                                         (250, 4096, 2048, "plain"), (300, 512, 256, "plain"), (24, 256, 128, "res"),
                                         (20, 2048, 2048, "plain"), (32, 6144, 1024, "swiglu_plain"), (64, 1024, 1024, "res"),
                                         (200, 2048, 6144, "ws_res"), (35, 2048, 6144, "ws_bias"), (100, 1024, 3072, "ws_res"),
-                                        (1000, 2048, 2048, "res")])
+                                        (1000, 2048, 2048, "res"), (24, 4096, 2048, "norm"), (32, 12288, 2048, "swiglu"),
+                                        (64, 4096, 1024, "norm"), (130, 6144, 1024, "swiglu"), (20, 1024, 1024, "norm")])
 def test_linear_prefill_row_counts(hip, M, N, K, kind):
     """Prefill-sized row counts (several 16-row tiles, ragged last tile) through every GEMM variant of the
     decoder stack, against the oracle."""
@@ -494,7 +495,8 @@ def test_fp8_pack_matches_torch_quantisation(hip):
                                         (8, 6144, 2048, "swiglu"), (8, 3072, 1024, "swiglu"), (5, 12288, 2048, "swiglu_plain"),
                                         (200, 4096, 2048, "plain"), (40, 2048, 2048, "res"), (200, 2048, 6144, "res"),
                                         (130, 1024, 3072, "bias"), (200, 6144, 2048, "swiglu_plain"), (32, 6144, 1024, "swiglu_plain"),
-                                        (128, 12288, 2048, "swiglu_plain")])
+                                        (128, 12288, 2048, "swiglu_plain"), (24, 4096, 2048, "norm"), (100, 6144, 1024, "swiglu"),
+                                        (64, 4096, 1024, "norm")])
 def test_linear_fp8_equals_bf16_on_dequantised_weights(hip, M, N, K, kind):
     """Every GEMM variant over fp8 weights returns bit for bit what the bf16 kernel returns on the dequantised
     weights q * scale (which are bf16 numbers), and the dequantised weights are the oracle's."""
