@@ -75,6 +75,8 @@ class PredictorModelRunner(ModelRunner):
                                ("tables", self.max_bs * mb, torch.int32)], self.device)
         # burst graphs: rows = 2*bs prefill rows followed by 14 groups of bs decode rows
         self.burst_bs = [b for b in [1, 2, 4, 8] if b <= self.max_bs] + list(range(16, self.max_bs + 1, 16))
+        if self.burst_bs[-1] < self.max_bs:                 # e.g. 3, 5..7, 9..15, 24: the largest batch is a bucket of its own
+            self.burst_bs.append(self.max_bs)
         self.burst_graphs: dict[int, hip.Graph] = {}
         rows = (2 + self.n_gen - 1) * self.max_bs
         self.bstage = Staging([("positions", rows, torch.int64), ("slots", rows, torch.int32),

@@ -52,6 +52,8 @@ class TalkerModeModelRunner(ModelRunner):
                                ("ctx", self.max_rows, torch.int32), ("row_seq", self.max_rows, torch.int32),
                                ("tables", self.max_bs * mb, torch.int32)], self.device)
         self.graph_bs = [b for b in [1, 2, 4, 8] if b <= self.max_bs] + list(range(16, self.max_bs + 1, 16))
+        if self.graph_bs[-1] < self.max_bs:                 # e.g. 3, 5..7, 9..15, 24: the largest batch is a bucket of its own
+            self.graph_bs.append(self.max_bs)
         self.graphs: dict[int, hip.Graph] = {}
 
     def _estimate_bytes(self, weights):

@@ -116,3 +116,29 @@ def test_capture_all_then_no_capture_while_serving(tmp_path):
         outs.append(frames)
         fe.exit()
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("max_streams", [3, 5, 24])
+def test_stream_counts_between_the_power_of_two_buckets(tmp_path, max_streams):
+    """An engine sized for 3, 5 or 24 streams (not one of the batch buckets 1, 2, 4, 8, 16, 32 ...) runs its full
+    batch, and every stream's ids equal a solo run of the same prompt."""
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    cfg, sd, tw, pw = golden_weights("tiny", 11)
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(max_streams)
+    H = cfg["talker_config"]["hidden_size"]
+    prompts = [torch.randn(5 + (i % 7), H, generator=gen) * 0.5 for i in range(max_streams)]
+    texts = [torch.randn(6, H, generator=gen) * 0.3 for _ in range(max_streams)]
+    kw = dict(max_text_frames=8, talker_weights=tw, predictor_weights=pw, max_num_batched_tokens=1024, codec_eos=None)
+    fe = FrameEngine(str(tmp_path), max_streams=max_streams, num_kvcache_blocks=max_streams + 1, **kw)
+    for p, t in zip(prompts, texts):
+        fe.add_stream(p, t, max_frames=4, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+    got = fe.run_frames(4).permute(1, 0, 2)[:max_streams].numpy()
+    fe.exit()
+    solo = FrameEngine(str(tmp_path), max_streams=1, num_kvcache_blocks=2, **kw)
+    for i in (0, max_streams - 1):
+        sid = solo.add_stream(prompts[i], texts[i], max_frames=4, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+        want = solo.run_frames(4).permute(1, 0, 2)[0].numpy()
+        solo.remove_stream(sid)
+        assert np.array_equal(got[i], want), i
+    solo.exit()

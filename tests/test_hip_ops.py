@@ -527,3 +527,22 @@ def test_linear_fp8_equals_bf16_on_dequantised_weights(hip, M, N, K, kind):
             want = hip.linear(x, wp, N, **kw)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("M,N,K", [(17, 2048, 2048), (32, 4096, 1024), (24, 1024, 3072), (32, 2048, 6144)])
+def test_prompt_gemm_with_two_row_tiles(hip, M, N, K):
+    """17..32 rows take single-tile workgroups by default; the prompt GEMM's two-row-tile form stays available
+    (qtts_tune_rows) and agrees with the oracle as well."""
+    g = torch.Generator().manual_seed(M * N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    wp = hip.pack_weight(w.to(DEV))
+    want = torch.nn.functional.linear(x, w)
+    for min_rows in (16, 32):
+        hip.lib.qtts_tune_rows(min_rows)
+        try:
+            got = hip.linear_ws(x.to(DEV), wp, N)
+            torch.cuda.synchronize()
+        finally:
+            hip.lib.qtts_tune_rows(32)
+        assert_bf16_close(got, want, what=f"rows from {min_rows + 1}")
