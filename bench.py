@@ -268,7 +268,7 @@ def main():
                          "bytes_per_launch": kbytes,
                          "us_per_launch": ksec * 1e6},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed beside the 1-GPU line only
             out["cpu_baseline"] = cpu_baseline(cfg, tw, pw, B, args.cpu_frames, 16)
         print(json.dumps(out), flush=True)
     fe.exit()
