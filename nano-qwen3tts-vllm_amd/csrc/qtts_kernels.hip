@@ -1600,9 +1600,13 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
     __shared__ float sm_l[NG][G];
     __shared__ int sm_last;
     const int row = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
+    const int t0 = split * SPLIT;
+    // A workgroup's tokens lie in one 256-token KV block (SPLIT divides 256): its table entry does not depend on the
+    // context length, so both are requested together instead of one round trip after the other.
+    static_assert(QTTS_KV_BLOCK % SPLIT == 0, "a workgroup's token range must not straddle KV blocks");
+    const int blk_all = p.block_tables[(size_t)row * p.max_blocks + (t0 >> 8)];
     const int ctx = p.context_lens[row];
     const int Hq = p.Hq, Hkv = p.Hkv;
-    const int t0 = split * SPLIT;
     if (ctx <= 0) {
         if (split == 0)
             for (int e = threadIdx.x; e < G * 128; e += NT) p.out[(size_t)row * p.ldo + (size_t)kvh * G * 128 + e] = 0;
@@ -1610,7 +1614,6 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
     }
     if (t0 >= ctx) return;
     const int nact = (ctx + SPLIT - 1) / SPLIT;   // splits of this row that hold tokens
-    const int32_t *bt = p.block_tables + (size_t)row * p.max_blocks;
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const bf16_t *rowp = p.qkv + (size_t)row * p.ld;
     long pos = p.positions[row];
@@ -1623,8 +1626,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
     for (int i = 0; i < TPG; ++i) {
         const int t = t0 + i * NG + grp;
         if (t < ctx - 1) {
-            const int blk = bt[t >> 8];
-            const size_t off = (((size_t)blk * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
+            const size_t off = (((size_t)blk_all * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
             kk[i].u = *reinterpret_cast<const uint4 *>(p.kc + off);
             vv[i].u = *reinterpret_cast<const uint4 *>(p.vc + off);
         } else {
