@@ -147,6 +147,8 @@ int qtts_store_kvcache(const void *k, int ldk, const void *v, int ldv, void *k_c
  * P/layers/attention.py:88-95: decode (one row per sequence, context_lens =
  * cache_seqlens) and causal prefill (context_lens[i] = position+1 after the
  * rows' K/V were stored).  context_lens[i] == 0 writes zeros.  fp32 softmax.
+ * With row_seq != NULL and at least 112 rows (prompts) 16 rows share a workgroup and
+ * the two contractions run on MFMA; otherwise one workgroup per (row, KV head).
  * workspace: qtts_attn_workspace_bytes(N, Hq, max_context) bytes of device scratch. */
 size_t qtts_attn_workspace_bytes(int N, int Hq, int max_context);
 int qtts_paged_attention(const void *q, int ldq, const void *k_cache, const void *v_cache,
