@@ -204,10 +204,19 @@ def main():
     H = cfg["talker_config"]["hidden_size"]
     fe = FrameEngine(mdir, max_streams=B, max_text_frames=n_frames + 1, talker_weights=tw, predictor_weights=pw,
                      num_kvcache_blocks=4 * B, max_num_batched_tokens=4096, codec_eos=None)
+    # as a server does at start-up (Qwen3TTSInterface.start_zmq_tasks): every frame graph this run can meet is captured
+    # before the first request, so first-chunk latency below is a replay, not a capture
+    fe.capture_all(max_context=min(1024, ((max(200, 0) + n_frames + 2 + 127) // 128) * 128))
     greedy_t = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
     greedy_p = SamplingParams(temperature=0.9, max_tokens=17, do_sample=False)
     lens = [16, 48, 128, 200]
     g = torch.Generator().manual_seed(1000 + rank)
+    # one warm-up request per prompt-kernel family (the reference's server fires warm-up requests too, E/server.py:276)
+    for L in (16, 200):
+        sid = fe.add_stream((torch.randn(L, H, generator=g) * 0.5).to(device), (torch.randn(4, H, generator=g) * 0.1).to(device),
+                            max_frames=4, talker_sampling=greedy_t, predictor_sampling=greedy_p)
+        fe.run_frames(1)
+        fe.remove_stream(sid)
     first_frame_ms = []
     prompt_lens = []
     for i in range(B):
