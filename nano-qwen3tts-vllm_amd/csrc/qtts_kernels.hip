@@ -433,6 +433,12 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             if (p.res && mvalid) resw = *reinterpret_cast<const uint2 *>(p.res + (size_t)m * p.ldr + 16 * t + 4 * g);
             if (p.bias) biasw = *reinterpret_cast<const uint2 *>(p.bias + 16 * t + 4 * g);
         }
+        // fp8 weights: the rows' power-of-two scales, requested up front for the same reason
+        float4_t wsc = {1.f, 1.f, 1.f, 1.f}, wsc_up = {1.f, 1.f, 1.f, 1.f};
+        if (W8 && wave == 0) {
+            wsc = *reinterpret_cast<const float4_t *>(tl.wscale + 16 * t + 4 * g);
+            if (EPI == 1 && g < 2) wsc_up = *reinterpret_cast<const float4_t *>(tl.wscale + 16 * t + 8 + 4 * g);
+        }
         // past the last tile the refills still execute (no branch) but all read one 1 KiB fragment that is in
         // the cache already
         const bool more = t + 2 < t_end;
@@ -460,12 +466,12 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             float4_t sum = red[lane];
             for (int w = 1; w < NW; ++w) sum += red[w * 64 + lane];
             // fp8 weights: the row's power-of-two scale, exact in fp32 (same result as bf16 weights q * scale)
-            if (W8) sum *= *reinterpret_cast<const float4_t *>(tl.wscale + 16 * t + 4 * g);
+            if (W8) sum *= wsc;
             if (EPI == 1) {
                 if (g < 2) {                              // lanes 0..31 hold gate rows; the up rows sit 32 lanes on
                     float4_t ups = red[lane + 32];
                     for (int w = 1; w < NW; ++w) ups += red[w * 64 + lane + 32];
-                    if (W8) ups *= *reinterpret_cast<const float4_t *>(tl.wscale + 16 * t + 8 + 4 * g);
+                    if (W8) ups *= wsc_up;
                     if (mvalid) {
                         float v[4];
 #pragma unroll
@@ -588,6 +594,13 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
             const int m = (by * TM + wave) * 16 + r;
             if (p.res && m < M) resw = *reinterpret_cast<const uint2 *>(p.res + (size_t)m * p.ldr + 16 * t + 4 * g);
         }
+        // fp8 weights: the rows' scales, requested here and not in the epilogue (a late load is waited for together
+        // with the weight tiles requested after it)
+        float4_t wsc = {1.f, 1.f, 1.f, 1.f}, wsc_up = {1.f, 1.f, 1.f, 1.f};
+        if (W8 && wave < TM) {
+            wsc = *reinterpret_cast<const float4_t *>(p.wscale + 16 * t + 4 * g);
+            if (EPI == 1 && g < 2) wsc_up = *reinterpret_cast<const float4_t *>(p.wscale + 16 * t + 8 + 4 * g);
+        }
         // unconditional: with straight-line code the compiler's wait counts let exactly the younger tile's loads
         // stay in flight; past the last tile the refills all read one 1 KiB fragment that is cached already
         const bool more = it + 2 < nt;
@@ -625,7 +638,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
         const int m = (by * TM + wave) * 16 + r;
         float4_t sum = mine[lane];
         for (int w = 1; w < NW; ++w) sum += mine[w * TM * 64 + lane];
-        if (W8) sum *= *reinterpret_cast<const float4_t *>(p.wscale + 16 * t + 4 * g);     // exact: powers of two
+        if (W8) sum *= wsc;                                // exact: powers of two
         if (EPI == 2) {
             if (m < M)
                 *reinterpret_cast<float4_t *>(p.part + ((size_t)blockIdx.y * p.mpad + m) * N + 16 * t + 4 * g) = sum;
@@ -635,7 +648,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
             if (g < 2) {                                  // lanes 0..31 hold gate rows; the up rows sit 32 lanes on
                 float4_t ups = mine[lane + 32];
                 for (int w = 1; w < NW; ++w) ups += mine[w * TM * 64 + lane + 32];
-                if (W8) ups *= *reinterpret_cast<const float4_t *>(p.wscale + 16 * t + 8 + 4 * g);
+                if (W8) ups *= wsc_up;
                 if (m < M) {
                     float v[4];
 #pragma unroll
@@ -651,18 +664,14 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
             return;
         }
         if (m < M) {
-            float v[4], rf[4], bfv[4];
-            uint2 biasw = make_uint2(0, 0);
-            if (p.bias) biasw = *reinterpret_cast<const uint2 *>(p.bias + 16 * t + 4 * g);
+            // (no bias here: a load this late is waited for with every younger request, i.e. with the weight tiles
+            // in flight for the next bodies; GEMMs with a bias take the single-tile kernel or the K-split epilogue)
+            float v[4], rf[4];
             unpack2(resw.x, rf[0], rf[1]);
             unpack2(resw.y, rf[2], rf[3]);
-            unpack2(biasw.x, bfv[0], bfv[1]);
-            unpack2(biasw.y, bfv[2], bfv[3]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float q = sum[j];
-                if (p.bias) q += bfv[j];
-                q = rbf(q);
+                float q = rbf(sum[j]);
                 if (p.res) q = q + rf[j];
                 v[j] = q;
             }
@@ -827,6 +836,7 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     }
     if (ksw != 4 && ksw != 8 && ksw != 12) return false;
     if (ksw == 12 && silu_pairs) return false;
+    if (a.bias && kparts == 1) return false;              // the single-pass epilogue carries no bias
     const int mtiles = (a.M + 15) / 16;
     const int TM = (mtiles <= 2 || ksw == 12) ? 2 : 4;
     RowsArgs r;
@@ -894,7 +904,7 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
         for (int c : ksws) if (c == g_tune_ksw) KSW = c;
     QCHECK(KSW > 0, "linear: K=%d not supported (K/32 must factor as <=8 waves x {1,2,4,6,8,12,24})", a.K);
     QCHECK(!(pro == 1 && KSW == 24), "linear: RMSNorm prologue not supported for K=%d", a.K);
-    QCHECK(!a.wscale || (KSW % 2 == 0 && pro != 2 && a.K % 64 == 0), "linear: fp8 weights need K %% 512 == 0 and no SwiGLU prologue (K=%d)", a.K);
+    QCHECK(!a.wscale || (KSW % 2 == 0 && pro != 2 && a.K % 64 == 0), "linear: fp8 weights need K %% 64 == 0, an even number of k-steps per wave and no SwiGLU prologue (K=%d)", a.K);
     const int NW = KS / KSW;
     const int ntiles = a.N / 16;
     int tpw = 1;
@@ -1150,6 +1160,7 @@ extern "C" int qtts_store_kvcache(const void *k, int ldk, const void *v, int ldv
 
 // ------------------------------------------------------------------ paged attention
 #define ATT_SPLIT 128   // tokens per workgroup
+static_assert(QTTS_KV_BLOCK % ATT_SPLIT == 0, "a workgroup's tokens must lie in one KV block");
 // grid (rows, Hkv, nsplit); 256 threads = 16 groups of 16 lanes; a group owns
 // tokens split*128 + i*16 + grp, i < 8; a lane owns 8 of the 128 head dims.
 template <int G>
@@ -1176,18 +1187,15 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
 
     Frag kk[8], vv[8];
+    // no branch around the loads (a conditional load is waited for inside its block, one round trip per token):
+    // lanes past the context repeat its last token, which the `valid` test below keeps out of the sums
+    const int blk_t0 = bt[t0 >> 8];                       // ATT_SPLIT divides the KV block: one table entry per workgroup
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int t = t0 + i * 16 + grp;
-        if (t < ctx) {
-            const int blk = bt[t >> 8];
-            const size_t base = (((size_t)blk * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
-            kk[i].u = *reinterpret_cast<const uint4 *>(kc + base);
-            vv[i].u = *reinterpret_cast<const uint4 *>(vc + base);
-        } else {
-            kk[i].u = make_uint4(0, 0, 0, 0);
-            vv[i].u = make_uint4(0, 0, 0, 0);
-        }
+        const int t = min(t0 + i * 16 + grp, ctx - 1);
+        const size_t base = (((size_t)blk_t0 * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
+        kk[i].u = *reinterpret_cast<const uint4 *>(kc + base);
+        vv[i].u = *reinterpret_cast<const uint4 *>(vc + base);
     }
     float qf[G][8];
 #pragma unroll
@@ -1293,8 +1301,8 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------ prompt attention on MFMA
-// Rows of a prompt, 16 at a time: grid (row tiles, Hkv), 8*G waves per workgroup; wave (tg, h) owns query head
-// kvh*G + h of the tile's 16 rows and every eighth 32-token step of the context (a step is a chain of dependent
+// Rows of a prompt, 16 at a time: grid (row tiles, Hkv), 8 waves per workgroup; wave (tg, h) owns query head
+// kvh*G + h of the tile's 16 rows and every (8/G)-th 32-token step of the context (a step is a chain of dependent
 // round trips, so the steps of a context run side by side rather than one after the other), the token groups merge
 // through LDS at the end (no partials in global memory, no combine launch).
 //   S^T[token][row] = K Q^T   A = 16 cached K rows (one 16-byte fragment per lane straight from the cache),
@@ -1308,13 +1316,16 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float *__restri
 // walked one after the other with the other rows masked.  Causality is context_lens[row] = position + 1.
 #define PA_VROW 272           // bytes of one V row in LDS: 4 rows apart = 16 banks, conflict-free transposed reads
 #define PA_WAVE_LDS (32 * PA_VROW)
-#define PA_NTG 8              // token groups (waves per query head) of a workgroup
+// Token groups (waves per query head) of a workgroup: eight waves in all, so that a wave may hold a step's K and V
+// fragments, the query rows and the accumulators at once (with sixteen waves the 128 registers each force the V
+// rows through one temporary, a round trip per row).
+#define PA_NTG(G) (8 / (G))
 template <int G>
-__global__ __launch_bounds__(64 * PA_NTG * G) void prefill_attn_mfma_kernel(
+__global__ __launch_bounds__(512) void prefill_attn_mfma_kernel(
     const bf16_t *__restrict__ q, int ldq, const bf16_t *__restrict__ kc, const bf16_t *__restrict__ vc,
     const int32_t *__restrict__ block_tables, int max_blocks, const int32_t *__restrict__ row_seq,
     const int32_t *__restrict__ context_lens, float scale, bf16_t *__restrict__ out, int ldo, int N, int Hkv) {
-    constexpr int NTG = PA_NTG;
+    constexpr int NTG = PA_NTG(G);
     constexpr float NEG = -1e30f;
     extern __shared__ unsigned char pa_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1354,29 +1365,40 @@ __global__ __launch_bounds__(64 * PA_NTG * G) void prefill_attn_mfma_kernel(
         const int32_t *bt = block_tables + (size_t)cur * max_blocks;
         const int nsteps = (cmax + 31) >> 5;
         const int climit = act ? ctx : 0;                                  // tokens this lane's row may see
+        // A 32-token step lies in one KV block (32 divides the block size), tokens clamped to the longest row's
+        // last one included (t0 <= cmax - 1): one table entry per step, requested one step ahead.
+        int blk_next = bt[min((min(tg, max(nsteps - 1, 0)) * 32) >> 8, max_blocks - 1)];
         for (int step = tg; step < nsteps; step += NTG) {
             const int t0 = step * 32;
+            const size_t bbase = (size_t)blk_next * QTTS_KV_BLOCK;
+            blk_next = bt[min((min(step + NTG, nsteps - 1) * 32) >> 8, max_blocks - 1)];
             // K fragments of the two 16-token tiles (tokens past the longest row re-read its last token: masked)
             Frag ka[4], kb[4];
             {
                 const int ta = min(t0 + r, cmax - 1), tb = min(t0 + 16 + r, cmax - 1);
-                const bf16_t *pa = kc + (((size_t)bt[min(ta >> 8, max_blocks - 1)] * QTTS_KV_BLOCK + (ta & 255)) * Hkv + kvh) * 128 + 8 * g;
-                const bf16_t *pb = kc + (((size_t)bt[min(tb >> 8, max_blocks - 1)] * QTTS_KV_BLOCK + (tb & 255)) * Hkv + kvh) * 128 + 8 * g;
+                const bf16_t *pa = kc + ((bbase + (ta & 255)) * Hkv + kvh) * 128 + 8 * g;
+                const bf16_t *pb = kc + ((bbase + (tb & 255)) * Hkv + kvh) * 128 + 8 * g;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     ka[ks].u = *reinterpret_cast<const uint4 *>(pa + 32 * ks);
                     kb[ks].u = *reinterpret_cast<const uint4 *>(pb + 32 * ks);
                 }
             }
-            // the 32 V rows into this wave's LDS region, as they lie in the cache
+            // the 32 V rows into this wave's LDS region, as they lie in the cache: all eight requests first, then the
+            // eight LDS writes (a write right behind its load makes every load a round trip of its own)
+            Frag vrow[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int tl = 4 * i + g;
-                const int tv = min(t0 + tl, cmax - 1);
-                const uint4 v = *reinterpret_cast<const uint4 *>(
-                    vc + (((size_t)bt[min(tv >> 8, max_blocks - 1)] * QTTS_KV_BLOCK + (tv & 255)) * Hkv + kvh) * 128 + 8 * r);
-                *reinterpret_cast<uint4 *>(vs + tl * PA_VROW + 16 * r) = v;
+                const int tv = min(t0 + 4 * i + g, cmax - 1);
+                vrow[i].u = *reinterpret_cast<const uint4 *>(vc + ((bbase + (tv & 255)) * Hkv + kvh) * 128 + 8 * r);
             }
+            // every row is in its registers before the first write: left to itself the compiler walks the rows
+            // through one temporary (load, wait, write, next load)
+            asm volatile("" : "+v"(vrow[0].v), "+v"(vrow[1].v), "+v"(vrow[2].v), "+v"(vrow[3].v), "+v"(vrow[4].v),
+                              "+v"(vrow[5].v), "+v"(vrow[6].v), "+v"(vrow[7].v));
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<uint4 *>(vs + (4 * i + g) * PA_VROW + 16 * r) = vrow[i].u;
             // the rows are read back two bytes at a time by other lanes of this wave: LDS serves a wave's requests in
             // order, the compiler must not move the differently-typed reads across the writes either
             asm volatile("" ::: "memory");
@@ -1497,16 +1519,16 @@ extern "C" int qtts_paged_attention(const void *q, int ldq, const void *k_cache,
         // several rows per sequence (a prompt): 16 rows per workgroup on MFMA.  Below about a hundred rows the
         // per-row kernel is faster (a 48-token prompt: 6.6 against 10 us per layer; 200 tokens: 25 against 14 us)
         const dim3 grid((N + 15) / 16, Hkv);
-        const size_t shmem = (size_t)PA_NTG * G * PA_WAVE_LDS;
+        const size_t shmem = (size_t)8 * PA_WAVE_LDS;                  // eight waves, whatever G is
         const void *kern = G == 1 ? reinterpret_cast<const void *>(&prefill_attn_mfma_kernel<1>)
                                   : reinterpret_cast<const void *>(&prefill_attn_mfma_kernel<2>);
         if (!allow_dynamic_lds(kern, shmem)) return QTTS_ESTATE;
         if (G == 1)
-            hipLaunchKernelGGL((prefill_attn_mfma_kernel<1>), grid, dim3(64 * PA_NTG), shmem, s, (const bf16_t *)q, ldq,
+            hipLaunchKernelGGL((prefill_attn_mfma_kernel<1>), grid, dim3(512), shmem, s, (const bf16_t *)q, ldq,
                                (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq,
                                context_lens, scale, (bf16_t *)out, ldo, N, Hkv);
         else
-            hipLaunchKernelGGL((prefill_attn_mfma_kernel<2>), grid, dim3(128 * PA_NTG), shmem, s, (const bf16_t *)q, ldq,
+            hipLaunchKernelGGL((prefill_attn_mfma_kernel<2>), grid, dim3(512), shmem, s, (const bf16_t *)q, ldq,
                                (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq,
                                context_lens, scale, (bf16_t *)out, ldo, N, Hkv);
         QLAUNCH();
@@ -1562,19 +1584,15 @@ struct AttnFusedArgs {
     int *counters;
 };
 
-__device__ __forceinline__ void norm_rope8(const float (&x)[8], const bf16_t *__restrict__ w, float eps, int l16,
-                                           const bf16_t *__restrict__ cosr, const bf16_t *__restrict__ sinr, float (&o)[8]) {
+// wv: the lane's 8 norm weights; cv, sv: its 8 cos / sin values (dims d and d + 64 share them)
+__device__ __forceinline__ void norm_rope8(const float (&x)[8], const Frag &wv, const Frag &cv, const Frag &sv, float eps,
+                                           int l16, float (&o)[8]) {
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
     ss = row16_sum(ss);
     const float rstd = 1.0f / sqrtf(ss / 128.0f + eps);
-    const int d0 = 8 * l16;
     const bool hi = l16 >= 8;                         // dims 64..127
-    Frag wv, cv, sv;
-    wv.u = *reinterpret_cast<const uint4 *>(w + d0);
-    cv.u = *reinterpret_cast<const uint4 *>(cosr + (d0 & 63));
-    sv.u = *reinterpret_cast<const uint4 *>(sinr + (d0 & 63));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float n = rbf(rbf(x[j] * rstd) * bf2f(wv.h[j]));
@@ -1582,6 +1600,17 @@ __device__ __forceinline__ void norm_rope8(const float (&x)[8], const bf16_t *__
         const float c = bf2f(cv.h[j]), sn = bf2f(sv.h[j]);
         o[j] = rbf(rbf(n * c) + rbf((hi ? partner : -partner) * sn));
     }
+}
+
+// the same with the weight / cos / sin rows given as pointers
+__device__ __forceinline__ void norm_rope8(const float (&x)[8], const bf16_t *__restrict__ w, float eps, int l16,
+                                           const bf16_t *__restrict__ cosr, const bf16_t *__restrict__ sinr, float (&o)[8]) {
+    const int d0 = 8 * l16;
+    Frag wv, cv, sv;
+    wv.u = *reinterpret_cast<const uint4 *>(w + d0);
+    cv.u = *reinterpret_cast<const uint4 *>(cosr + (d0 & 63));
+    sv.u = *reinterpret_cast<const uint4 *>(sinr + (d0 & 63));
+    norm_rope8(x, wv, cv, sv, eps, l16, o);
 }
 
 __device__ __forceinline__ float ld_agent(const float *p) {
@@ -1598,7 +1627,9 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
     __shared__ float sm_acc[NG][G][128];
     __shared__ float sm_m[NG][G];
     __shared__ float sm_l[NG][G];
+    __shared__ __attribute__((aligned(16))) float sm_q[G + 1][128];
     __shared__ int sm_last;
+    static_assert(NG >= G + 1, "one sixteen-lane group per head row to normalise");
     const int row = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
     const int t0 = split * SPLIT;
     // A workgroup's tokens lie in one 256-token KV block (SPLIT divides 256): its table entry does not depend on the
@@ -1606,7 +1637,21 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
     static_assert(QTTS_KV_BLOCK % SPLIT == 0, "a workgroup's token range must not straddle KV blocks");
     const int blk_all = p.block_tables[(size_t)row * p.max_blocks + (t0 >> 8)];
     const int ctx = p.context_lens[row];
+    const int slot = p.slots ? p.slots[row] : -1;
+    long pos = p.positions[row];
     const int Hq = p.Hq, Hkv = p.Hkv;
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    // The G query heads and the new token's K are normalised and rotated once per workgroup, by the first G + 1
+    // sixteen-lane groups (one head row each), and handed to the others through LDS: every group doing all of
+    // them itself is G + 1 times the arithmetic on each SIMD, between the arrival of the row and the first score.
+    // The row and the norm weights depend on no metadata and are requested with it (the other groups request the K
+    // row as well and drop it: no branch around the loads).
+    const bf16_t *rowp = p.qkv + (size_t)row * p.ld;
+    const bool isq = grp < G;
+    Frag xr, wv, vnew;
+    xr.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(isq ? kvh * G + grp : Hq + kvh) * 128 + 8 * l16);
+    wv.u = *reinterpret_cast<const uint4 *>((isq ? p.qw : p.kw) + 8 * l16);
+    vnew.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(Hq + Hkv + kvh) * 128 + 8 * l16);
     if (ctx <= 0) {
         if (split == 0)
             for (int e = threadIdx.x; e < G * 128; e += NT) p.out[(size_t)row * p.ldo + (size_t)kvh * G * 128 + e] = 0;
@@ -1614,55 +1659,60 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
     }
     if (t0 >= ctx) return;
     const int nact = (ctx + SPLIT - 1) / SPLIT;   // splits of this row that hold tokens
-    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const bf16_t *rowp = p.qkv + (size_t)row * p.ld;
-    long pos = p.positions[row];
     pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);      // metadata is device data: never index past the table
-    const bf16_t *cosr = p.cosT + pos * 64, *sinr = p.sinT + pos * 64;
+    Frag cv, sv;
+    cv.u = *reinterpret_cast<const uint4 *>(p.cosT + pos * 64 + ((8 * l16) & 63));
+    sv.u = *reinterpret_cast<const uint4 *>(p.sinT + pos * 64 + ((8 * l16) & 63));
 
-    // cached K/V are requested before the norm/rope arithmetic
+    // Cached K/V are requested before the norm/rope arithmetic, behind what that arithmetic waits for, and without
+    // a branch: a load under a condition is followed by the wait for it inside the conditional block (the merge
+    // with the "no token" value), i.e. one round trip per token instead of all requests in flight together.  A
+    // lane without a cached token (the new token, or past the context) reads this row's raw k/v instead: finite
+    // values whose weight is zero, and for the new token V as it is wanted.
     Frag kk[TPG], vv[TPG];
+    const bf16_t *krow = rowp + (size_t)(Hq + kvh) * 128 + 8 * l16;
+    const bf16_t *vrow = rowp + (size_t)(Hq + Hkv + kvh) * 128 + 8 * l16;
 #pragma unroll
     for (int i = 0; i < TPG; ++i) {
         const int t = t0 + i * NG + grp;
-        if (t < ctx - 1) {
-            const size_t off = (((size_t)blk_all * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
-            kk[i].u = *reinterpret_cast<const uint4 *>(p.kc + off);
-            vv[i].u = *reinterpret_cast<const uint4 *>(p.vc + off);
-        } else {
-            kk[i].u = make_uint4(0, 0, 0, 0);
-            vv[i].u = make_uint4(0, 0, 0, 0);
-        }
+        const bool cached = t < ctx - 1;
+        const size_t off = (((size_t)blk_all * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
+        kk[i].u = *reinterpret_cast<const uint4 *>(cached ? p.kc + off : krow);
+        vv[i].u = *reinterpret_cast<const uint4 *>(cached ? p.vc + off : vrow);
     }
 
-    float qf[G][8];
+    Frag knew;
+    if (grp <= G) {
+        float x[8], o[8];
 #pragma unroll
-    for (int h = 0; h < G; ++h) {
-        Frag f;
-        f.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(kvh * G + h) * 128 + 8 * l16);
-        float x[8];
+        for (int j = 0; j < 8; ++j) x[j] = bf2f(xr.h[j]);
+        norm_rope8(x, wv, cv, sv, p.eps, l16, o);
+        *reinterpret_cast<float4 *>(&sm_q[grp][8 * l16]) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(&sm_q[grp][8 * l16 + 4]) = make_float4(o[4], o[5], o[6], o[7]);
+        // the new token (index ctx-1) goes to its cache slot: K normalised + rotated (exactly representable in
+        // bf16), V as is
+        if (!isq && slot >= 0 && (ctx - 1) >= t0 && (ctx - 1) < t0 + SPLIT) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = bf2f(f.h[j]);
-        norm_rope8(x, p.qw, p.eps, l16, cosr, sinr, qf[h]);
-    }
-    // the new token (index ctx-1): K normalised + rotated (exactly representable in bf16), V as is
-    Frag knew, vnew;
-    {
-        Frag f;
-        f.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(Hq + kvh) * 128 + 8 * l16);
-        vnew.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(Hq + Hkv + kvh) * 128 + 8 * l16);
-        float x[8], kn[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = bf2f(f.h[j]);
-        norm_rope8(x, p.kw, p.eps, l16, cosr, sinr, kn);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) knew.h[j] = f2bf(kn[j]);
-        const int slot = p.slots ? p.slots[row] : -1;
-        if (slot >= 0 && grp == 0 && (ctx - 1) >= t0 && (ctx - 1) < t0 + SPLIT) {
+            for (int j = 0; j < 8; ++j) knew.h[j] = f2bf(o[j]);
             const size_t off = ((size_t)slot * Hkv + kvh) * 128 + 8 * l16;
             *reinterpret_cast<uint4 *>(p.kc + off) = knew.u;
             *reinterpret_cast<uint4 *>(p.vc + off) = vnew.u;
         }
+    }
+    __syncthreads();
+    float qf[G][8];
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+        const float4 a = *reinterpret_cast<const float4 *>(&sm_q[h][8 * l16]);
+        const float4 b = *reinterpret_cast<const float4 *>(&sm_q[h][8 * l16 + 4]);
+        qf[h][0] = a.x; qf[h][1] = a.y; qf[h][2] = a.z; qf[h][3] = a.w;
+        qf[h][4] = b.x; qf[h][5] = b.y; qf[h][6] = b.z; qf[h][7] = b.w;
+    }
+    {
+        const float4 a = *reinterpret_cast<const float4 *>(&sm_q[G][8 * l16]);
+        const float4 b = *reinterpret_cast<const float4 *>(&sm_q[G][8 * l16 + 4]);
+        knew.h[0] = f2bf(a.x); knew.h[1] = f2bf(a.y); knew.h[2] = f2bf(a.z); knew.h[3] = f2bf(a.w);
+        knew.h[4] = f2bf(b.x); knew.h[5] = f2bf(b.y); knew.h[6] = f2bf(b.z); knew.h[7] = f2bf(b.w);
     }
 
     // scores of the group's tokens, then one maximum, then the exponentials
@@ -1674,10 +1724,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
         for (int h = 0; h < G; ++h) sc[i][h] = -INFINITY;
         if (i >= rounds) continue;
         const int t = t0 + i * NG + grp;
-        if (t == ctx - 1) {
-            kk[i].u = knew.u;
-            vv[i].u = vnew.u;
-        }
+        if (t == ctx - 1) kk[i].u = knew.u;            // its V is the raw row already loaded in its place
 #pragma unroll
         for (int h = 0; h < G; ++h) {
             float s = 0.f;
