@@ -2006,12 +2006,38 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const bf16_t *__restri
     // maximum (and its lowest index) while staging
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += 256) {
-        const float v = bf2f(logits[(size_t)row * ld + i]) / T;
-        val[i] = v;
-        if (v > best) {               // ascending i per thread: the first maximum is kept
-            best = v;
-            bi = i;
+    const bf16_t *lr = logits + (size_t)row * ld;
+    if (((V | ld) & 7) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+        // 16 bytes per request and both of a thread's requests (V <= 4096: at most two) out before the first
+        // is used: one round trip for the row instead of one per element a thread owns
+        const int nch = V >> 3;
+        Frag f[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            f[c].u = *reinterpret_cast<const uint4 *>(lr + 8 * min((int)threadIdx.x + 256 * c, nch - 1));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = threadIdx.x + 256 * c;
+            if (ch < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = bf2f(f[c].h[j]) / T;
+                    val[8 * ch + j] = v;
+                    if (v > best) {       // ascending index per thread: the first maximum is kept
+                        best = v;
+                        bi = 8 * ch + j;
+                    }
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < V; i += 256) {
+            const float v = bf2f(lr[i]) / T;
+            val[i] = v;
+            if (v > best) {               // ascending i per thread: the first maximum is kept
+                best = v;
+                bi = i;
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
