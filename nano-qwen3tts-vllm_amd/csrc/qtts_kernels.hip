@@ -1620,8 +1620,16 @@ __device__ __forceinline__ void st_agent(float *p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The first arguments are what the first loads need (16 dwords: they arrive in SGPRs with the wave, the struct
+// behind them is fetched from the argument buffer); `p` repeats them for the host's convenience.
 template <int G, int NG, int TPG = ATT2_SPLIT / NG>
-__global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFusedArgs p) {
+__global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_t *__restrict__ a_ctx,
+                                                                    const int32_t *__restrict__ a_tables,
+                                                                    const int64_t *__restrict__ a_pos,
+                                                                    const int32_t *__restrict__ a_slots,
+                                                                    const bf16_t *__restrict__ a_qkv, int a_max_blocks,
+                                                                    int a_ld, int a_Hq, int a_Hkv, int a_max_pos,
+                                                                    int a_nsplit, const AttnFusedArgs p) {
     constexpr int SPLIT = NG * TPG;                    // tokens per workgroup; TPG = tokens a 16-lane group walks
     constexpr int NT = NG * 16;
     __shared__ float sm_acc[NG][G][128];
@@ -1635,18 +1643,25 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
     // A workgroup's tokens lie in one 256-token KV block (SPLIT divides 256): its table entry does not depend on the
     // context length, so both are requested together instead of one round trip after the other.
     static_assert(QTTS_KV_BLOCK % SPLIT == 0, "a workgroup's token range must not straddle KV blocks");
-    const int blk_all = p.block_tables[(size_t)row * p.max_blocks + (t0 >> 8)];
-    const int ctx = p.context_lens[row];
-    const int slot = p.slots ? p.slots[row] : -1;
-    long pos = p.positions[row];
-    const int Hq = p.Hq, Hkv = p.Hkv;
+    // the row's metadata: four independent requests in one batch, no branch between them (a null slot array reads
+    // the context length in its place and is sorted out afterwards)
+    const int blk_all = a_tables[(size_t)row * a_max_blocks + (t0 >> 8)];
+    const int ctx = a_ctx[row];
+    const int slot_raw = (a_slots ? a_slots : a_ctx)[row];
+    long pos = a_pos[row];
+    // One wait for the whole batch, the struct's pointers included: without this the compiler moves each request
+    // down to its first use, behind the early exits, and the wave pays one round trip after the other.
+    asm volatile("" ::"s"(blk_all), "s"(ctx), "s"(slot_raw), "s"(pos), "s"(p.kc), "s"(p.vc), "s"(p.cosT), "s"(p.sinT),
+                 "s"(p.qw), "s"(p.kw), "s"(p.out));
+    const int slot = a_slots ? slot_raw : -1;
+    const int Hq = a_Hq, Hkv = a_Hkv;
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     // The G query heads and the new token's K are normalised and rotated once per workgroup, by the first G + 1
     // sixteen-lane groups (one head row each), and handed to the others through LDS: every group doing all of
     // them itself is G + 1 times the arithmetic on each SIMD, between the arrival of the row and the first score.
     // The row and the norm weights depend on no metadata and are requested with it (the other groups request the K
     // row as well and drop it: no branch around the loads).
-    const bf16_t *rowp = p.qkv + (size_t)row * p.ld;
+    const bf16_t *rowp = a_qkv + (size_t)row * a_ld;
     const bool isq = grp < G;
     Frag xr, wv, vnew;
     xr.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(isq ? kvh * G + grp : Hq + kvh) * 128 + 8 * l16);
@@ -1659,7 +1674,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
     }
     if (t0 >= ctx) return;
     const int nact = (ctx + SPLIT - 1) / SPLIT;   // splits of this row that hold tokens
-    pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);      // metadata is device data: never index past the table
+    pos = pos < 0 ? 0 : (pos >= a_max_pos ? a_max_pos - 1 : pos);      // metadata is device data: never index past the table
     Frag cv, sv;
     cv.u = *reinterpret_cast<const uint4 *>(p.cosT + pos * 64 + ((8 * l16) & 63));
     sv.u = *reinterpret_cast<const uint4 *>(p.sinT + pos * 64 + ((8 * l16) & 63));
@@ -1786,7 +1801,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
         if (direct) {
             p.out[(size_t)row * p.ldo + (size_t)hq * 128 + d] = f2bf(o / L);
         } else {
-            const size_t pi = ((size_t)row * Hq + hq) * p.nsplit + split;
+            const size_t pi = ((size_t)row * Hq + hq) * a_nsplit + split;
             st_agent(p.part_o + pi * 128 + d, o);
             if (d == 0) {
                 st_agent(p.part_ml + pi * 2 + 0, M);
@@ -1810,7 +1825,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const AttnFu
     for (int e = threadIdx.x; e < G * 128; e += NT) {
         const int h = e >> 7, d = e & 127;
         const int hq = kvh * G + h;
-        const size_t p0 = ((size_t)row * Hq + hq) * p.nsplit;
+        const size_t p0 = ((size_t)row * Hq + hq) * a_nsplit;
         float M = -INFINITY;
         for (int s = 0; s < nact; ++s) M = fmaxf(M, ld_agent(p.part_ml + (p0 + s) * 2));
         float L = 0.f, o = 0.f;
@@ -1861,15 +1876,15 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
     dim3 grid(B, Hkv, ns);
     switch (Hq / Hkv) {
         // short contexts (the code predictor's 17 tokens) leave most of a 32-group workgroup idle
-        case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 16>), grid, dim3(256), 0, s, a);
-                else if (wide) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32, 8>), grid, dim3(512), 0, s, a);
-                else hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32>), grid, dim3(512), 0, s, a);
+        case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 16>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+                else if (wide) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32, 8>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+                else hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                 break;
-        case 2: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 16>), grid, dim3(256), 0, s, a);
-                else if (wide) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 32, 8>), grid, dim3(512), 0, s, a);
-                else hipLaunchKernelGGL((attn_decode_fused_kernel<2, 32>), grid, dim3(512), 0, s, a);
+        case 2: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 16>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+                else if (wide) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 32, 8>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+                else hipLaunchKernelGGL((attn_decode_fused_kernel<2, 32>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                 break;
-        case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<4, 16>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<4, 16>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
         default: QFAIL(QTTS_EINVAL, "attention_decode_fused: unsupported q/kv head ratio %d", Hq / Hkv);
     }
     QLAUNCH();
@@ -1987,11 +2002,12 @@ __device__ __forceinline__ T block_scan256(T v, T *sm) {
 // (P/layers/sampler.py:15-24: logits / T, everything below the k-th largest value removed, softmax, one draw):
 // the k-th largest value by a 4-pass radix select over the order-preserving keys (a 256-bin histogram per byte),
 // then the inverse CDF in index order with a chunk of consecutive indices per thread and a workgroup prefix sum.
-__global__ __launch_bounds__(256) void sample_topk_kernel(const bf16_t *__restrict__ logits, int ld,
-                                                          const float *__restrict__ temps, int top_k, uint64_t seed,
-                                                          uint64_t offset, const uint64_t *__restrict__ offset_dev,
-                                                          const uint8_t *__restrict__ greedy, int64_t *__restrict__ out,
-                                                          int ldout, int V) {
+// Argument order: what the first requests need comes first (the leading 16 dwords arrive in SGPRs with the wave).
+__global__ __launch_bounds__(256) void sample_topk_kernel(const bf16_t *__restrict__ logits, int ld, int V,
+                                                          const float *__restrict__ temps,
+                                                          const uint8_t *__restrict__ greedy,
+                                                          const uint64_t *__restrict__ offset_dev, int top_k, int ldout,
+                                                          int64_t *__restrict__ out, uint64_t seed, uint64_t offset) {
     __shared__ float val[4096];
     __shared__ int hist[256];
     __shared__ float wv[4];
@@ -2000,21 +2016,29 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const bf16_t *__restri
     __shared__ float fs[4];
     __shared__ int picked;
     const int row = blockIdx.x;
-    const bool is_greedy = greedy && greedy[row];
-    const float T = is_greedy ? 1.0f : temps[row];
-    if (offset_dev) offset += *offset_dev;
+    const bf16_t *lr = logits + (size_t)row * ld;
+    const bool vec = ((V | ld) & 7) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
+    // Every request of the prologue goes out before the first wait: the row (16 bytes per request, at most two per
+    // thread for V <= 4096), the row's greedy flag and temperature, the RNG offset.  Optional arrays that are absent
+    // read a valid word in their place (sorted out below), so no request sits behind a branch.
+    const int nch = V >> 3;
+    Frag f[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        f[c].u = *reinterpret_cast<const uint4 *>(
+            vec ? lr + 8 * min((int)threadIdx.x + 256 * c, nch - 1)
+                : reinterpret_cast<const bf16_t *>(reinterpret_cast<uintptr_t>(logits) & ~(uintptr_t)15));   // unused
+    const uint8_t gflag = (greedy ? greedy + row : reinterpret_cast<const uint8_t *>(temps))[0];
+    const float Traw = temps[row];
+    const uint64_t odev = *(offset_dev ? offset_dev : reinterpret_cast<const uint64_t *>(out));
+    asm volatile("" ::"v"((int)gflag), "s"(Traw), "s"(odev));
+    const bool is_greedy = greedy && gflag;
+    const float T = is_greedy ? 1.0f : Traw;
+    if (offset_dev) offset += odev;
     // maximum (and its lowest index) while staging
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    const bf16_t *lr = logits + (size_t)row * ld;
-    if (((V | ld) & 7) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
-        // 16 bytes per request and both of a thread's requests (V <= 4096: at most two) out before the first
-        // is used: one round trip for the row instead of one per element a thread owns
-        const int nch = V >> 3;
-        Frag f[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-            f[c].u = *reinterpret_cast<const uint4 *>(lr + 8 * min((int)threadIdx.x + 256 * c, nch - 1));
+    if (vec) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int ch = threadIdx.x + 256 * c;
@@ -2145,8 +2169,8 @@ extern "C" int qtts_pick_token(const void *logits, int ld, const float *temperat
     QCHECK(logits && temperatures && out && M > 0 && V > 0 && ld >= V && ldout >= 1, "pick_token: bad arguments");
     QCHECK(V <= 4096, "pick_token: V=%d > 4096", V);
     QCHECK(top_k >= 1 && top_k <= V, "pick_token: top_k=%d out of range", top_k);
-    hipLaunchKernelGGL(sample_topk_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)logits, ld,
-                       temperatures, top_k, seed, offset, offset_dev, greedy_flags, out, ldout, V);
+    hipLaunchKernelGGL(sample_topk_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)logits, ld, V,
+                       temperatures, greedy_flags, offset_dev, top_k, ldout, out, seed, offset);
     QLAUNCH();
     return QTTS_OK;
 }
