@@ -267,6 +267,22 @@ int qtts_model_forward_logits(qtts_model_t *m, const void *x, const int64_t *pos
                               const int32_t *context_lens, const int32_t *block_tables, int max_blocks,
                               int max_context, int N, void *hidden_out, const void *head_w_packed,
                               int vocab, void *logits_out, qtts_stream_t stream);
+/* A decode step (N <= 16 rows, one per sequence) whose input rows are rows of a table: row r = x_table[ids[r]],
+ * x_table [table_rows, hidden] bf16, read in place by layer 0 (qkv GEMM input, o_proj residual); ids are device
+ * data and clamped to the table.  qkv0_table (may be NULL) [table_rows, (Hq+2Hkv)*128] holds, per table row,
+ * layer 0's input norm + qkv projection of that row; with it layer 0's qkv GEMM is not launched and its
+ * attention reads the table rows (needs max_context <= 32 unless Hq/Hkv == 4).  Both tables are functions of the
+ * weights only: for the code predictor x_table[i] = small_to_mtp_projection(codec_embedding[i].weight) and
+ * qkv0_table[i] = qkv_proj(input_layernorm(x_table[i])) of layer 0, built once at load with the library's own
+ * GEMMs, so a step returns the same bits as gathering and projecting on the fly
+ * (get_input_embeddings P/models/qwen3_tts_predictor.py:87-99, projection :58-61,106, layer body
+ * P/models/qwen3_tts_share.py:96-103,160-176). */
+int qtts_model_forward_logits_gathered(qtts_model_t *m, const void *x_table, const void *qkv0_table,
+                                       const int64_t *ids, int table_rows, const int64_t *positions,
+                                       const int32_t *slot_mapping, const int32_t *context_lens,
+                                       const int32_t *block_tables, int max_blocks, int max_context, int N,
+                                       void *hidden_out, const void *head_w_packed, int vocab,
+                                       void *logits_out, qtts_stream_t stream);
 
 /* ---------------------------------------------------------------- resident burst
  * The code predictor's whole burst for up to 8 sequences — the 2-position prefill and

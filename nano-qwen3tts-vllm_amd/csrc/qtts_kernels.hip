@@ -239,6 +239,7 @@ struct LinArgs {
     int M, N, K, tiles_per_wg;
     const bf16_t *next_nw = nullptr; bf16_t *next_xn = nullptr; int ldnn = 0;   // K-split prompt GEMM only: also RMSNorm(out) * next_nw
     const float *wscale = nullptr;   // non-null: wp holds fp8 (e4m3) weights, two k-steps per 16-byte fragment; scale per packed row
+    const int64_t *res_ids = nullptr; int res_id_rows = 0;   // non-null: residual row m = res[res_ids[m]] (decode GEMM only)
     int dbg;      // bit0: tuning experiment (every tile reads weight tile 0); bits 8+: row-tile count of a prefill launch
 };
 
@@ -273,6 +274,7 @@ struct LinTail {
     bf16_t *out; int ldo;
     long long *trace;     // tuning experiments only (null in production): 4 timestamps per workgroup
     const float *wscale;  // fp8 weights: one power-of-two scale per packed weight row
+    const int64_t *res_ids; int res_id_rows;   // residual rows gathered from a table (null: row m)
 };
 #define QTTS_TRACE(slot) do { if (tl.trace && threadIdx.x == 0) tl.trace[(size_t)blockIdx.x * 4 + (slot)] = wall_clock64(); } while (0)
 
@@ -332,6 +334,12 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             rid = rid < 0 ? 0 : (rid >= p.id_rows ? p.id_rows - 1 : rid);
         }
         xrow = (size_t)rid * p.ldx;
+    }
+    size_t rrow = (size_t)m * p.ldr;
+    if (EPI == 0 && tl.res_ids) {
+        long rid = tl.res_ids[mvalid ? m : 0];
+        rid = rid < 0 ? 0 : (rid >= tl.res_id_rows ? tl.res_id_rows - 1 : rid);
+        rrow = (size_t)rid * p.ldr;
     }
     const bf16_t *xp = p.x + xrow + 32 * ks0 + 8 * g;
 #pragma unroll
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         // epilogue does not start another memory round trip after the reduction
         uint2 resw = make_uint2(0, 0), biasw = make_uint2(0, 0);
         if (EPI == 0 && wave == 0 && orow) {
-            if (p.res && mvalid) resw = *reinterpret_cast<const uint2 *>(p.res + (size_t)m * p.ldr + 16 * t + 4 * g);
+            if (p.res && mvalid) resw = *reinterpret_cast<const uint2 *>(p.res + rrow + 16 * t + 4 * g);
             if (p.bias) biasw = *reinterpret_cast<const uint2 *>(p.bias + 16 * t + 4 * g);
         }
         // fp8 weights: the rows' power-of-two scales, requested up front for the same reason
@@ -785,6 +793,7 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
         ++g_trace_launch;
     }
     tl.wscale = a.wscale;
+    tl.res_ids = a.res_ids; tl.res_id_rows = a.res_id_rows;
     if constexpr (KSW % 2 == 0 && PRO != 2) {
         if (a.wscale) {
             hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI, SUB, true>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids,
@@ -890,6 +899,7 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     QCHECK(pro != 1 || a.nw, "linear: norm prologue without weight");
     QCHECK(!a.xnorm_out || (a.ldxn % 8 == 0 && a.ldxn >= a.K), "linear: bad xnorm_out stride");
     // from three row tiles on; with two, single-tile workgroups are faster (a frame at 32 streams: 4.79 against 5.01 ms)
+    QCHECK(!a.res_ids || (a.M <= 16 && a.res && a.res_id_rows > 0), "linear: gathered residual rows need M <= 16 and a residual table");
     if (a.M > g_rows_min && pro == 0 && !a.ids && !(g_dbg_linear & 2) && launch_linear_rows(a, silu_pairs, scratch, scratch_bytes, s)) {
         QLAUNCH();
         return QTTS_OK;
@@ -1582,6 +1592,7 @@ struct AttnFusedArgs {
     int Hq, Hkv;
     float *part_o, *part_ml; int nsplit;
     int *counters;
+    const int64_t *row_ids; int id_rows;   // non-null: row r of the launch reads qkv row row_ids[r] (a table of rows)
 };
 
 // wv: the lane's 8 norm weights; cv, sv: its 8 cos / sin values (dims d and d + 64 share them)
@@ -1622,7 +1633,9 @@ __device__ __forceinline__ void st_agent(float *p, float v) {
 
 // The first arguments are what the first loads need (16 dwords: they arrive in SGPRs with the wave, the struct
 // behind them is fetched from the argument buffer); `p` repeats them for the host's convenience.
-template <int G, int NG, int TPG = ATT2_SPLIT / NG>
+// IDS: the qkv rows come from a table, row r of the launch is table row p.row_ids[r] (one more dependent request
+// in front of the row loads; everything else is unchanged).
+template <int G, int NG, int TPG = ATT2_SPLIT / NG, bool IDS = false>
 __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_t *__restrict__ a_ctx,
                                                                     const int32_t *__restrict__ a_tables,
                                                                     const int64_t *__restrict__ a_pos,
@@ -1649,10 +1662,12 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
     const int ctx = a_ctx[row];
     const int slot_raw = (a_slots ? a_slots : a_ctx)[row];
     long pos = a_pos[row];
+    long qrow = IDS ? p.row_ids[row] : row;
     // One wait for the whole batch, the struct's pointers included: without this the compiler moves each request
     // down to its first use, behind the early exits, and the wave pays one round trip after the other.
     asm volatile("" ::"s"(blk_all), "s"(ctx), "s"(slot_raw), "s"(pos), "s"(p.kc), "s"(p.vc), "s"(p.cosT), "s"(p.sinT),
-                 "s"(p.qw), "s"(p.kw), "s"(p.out));
+                 "s"(p.qw), "s"(p.kw), "s"(p.out), "s"(qrow));
+    if (IDS) qrow = qrow < 0 ? 0 : (qrow >= p.id_rows ? p.id_rows - 1 : qrow);
     const int slot = a_slots ? slot_raw : -1;
     const int Hq = a_Hq, Hkv = a_Hkv;
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -1661,7 +1676,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
     // them itself is G + 1 times the arithmetic on each SIMD, between the arrival of the row and the first score.
     // The row and the norm weights depend on no metadata and are requested with it (the other groups request the K
     // row as well and drop it: no branch around the loads).
-    const bf16_t *rowp = a_qkv + (size_t)row * a_ld;
+    const bf16_t *rowp = a_qkv + (size_t)qrow * a_ld;
     const bool isq = grp < G;
     Frag xr, wv, vnew;
     xr.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(isq ? kvh * G + grp : Hq + kvh) * 128 + 8 * l16);
@@ -1850,7 +1865,7 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
                                        void *v_cache, const int32_t *block_tables, int max_blocks,
                                        const int32_t *context_lens, int max_context, float scale, void *out,
                                        int ldo, int B, int Hq, int Hkv, void *partials, int *counters,
-                                       hipStream_t s) {
+                                       hipStream_t s, const int64_t *row_ids = nullptr, int id_rows = 0) {
     QCHECK(qkv && q_norm_w && k_norm_w && rope_cos && rope_sin && positions && k_cache && v_cache && block_tables &&
                context_lens && out, "attention_decode_fused: null pointer");
     QCHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && ldqkv % 8 == 0 && ldqkv >= (Hq + 2 * Hkv) * 128 &&
@@ -1873,7 +1888,20 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
     a.context_lens = context_lens; a.scale = scale; a.out = (bf16_t *)out; a.ldo = ldo; a.Hq = Hq; a.Hkv = Hkv;
     a.part_o = (float *)partials; a.part_ml = a.part_o ? a.part_o + (size_t)B * Hq * ns * 128 : nullptr; a.nsplit = ns;
     a.counters = counters;
+    a.row_ids = row_ids; a.id_rows = id_rows;
     dim3 grid(B, Hkv, ns);
+    if (row_ids) {
+        // rows gathered from a table: built for the one-workgroup-per-(row, kv head) variants
+        QCHECK(id_rows > 0 && (max_context <= 32 || Hq / Hkv == 4), "attention_decode_fused: gathered rows need max_context <= 32 (got %d)", max_context);
+        switch (Hq / Hkv) {
+            case 1: hipLaunchKernelGGL((attn_decode_fused_kernel<1, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
+            case 2: hipLaunchKernelGGL((attn_decode_fused_kernel<2, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
+            case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<4, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
+            default: QFAIL(QTTS_EINVAL, "attention_decode_fused: unsupported q/kv head ratio %d", Hq / Hkv);
+        }
+        QLAUNCH();
+        return QTTS_OK;
+    }
     switch (Hq / Hkv) {
         // short contexts (the code predictor's 17 tokens) leave most of a 32-group workgroup idle
         case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 16>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
@@ -2310,10 +2338,12 @@ struct LayerW {
 static int stack_linear(const void *x, int ldx, const void *w, const float *wscale, const void *residual, int ldr,
                         const void *norm_w, float eps, void *out, int ldo, int M, int N, int K, float *scratch,
                         size_t scratch_bytes, qtts_stream_t stream, const void *next_norm_w = nullptr,
-                        void *next_xn = nullptr, int ldnn = 0) {
+                        void *next_xn = nullptr, int ldnn = 0, const int64_t *x_ids = nullptr,
+                        const int64_t *res_ids = nullptr, int id_rows = 0) {
     LinArgs a;
     a.next_nw = (const bf16_t *)next_norm_w; a.next_xn = (bf16_t *)next_xn; a.ldnn = ldnn;
-    a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0; a.wp = (const uint4 *)w; a.wscale = wscale;
+    a.res_ids = res_ids; a.res_id_rows = res_ids ? id_rows : 0;
+    a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = x_ids; a.id_rows = x_ids ? id_rows : 0; a.wp = (const uint4 *)w; a.wscale = wscale;
     a.bias = nullptr; a.res = (const bf16_t *)residual; a.ldr = ldr; a.nw = (const bf16_t *)norm_w; a.eps = eps;
     a.xnorm_out = nullptr; a.ldxn = 0; a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.tiles_per_wg = 1;
     return launch_linear2(a, norm_w ? 1 : 0, (hipStream_t)stream, false, scratch, scratch_bytes);
@@ -2469,8 +2499,14 @@ extern "C" int qtts_model_set_workspace(qtts_model_t *m, void *ws, size_t bytes,
 static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *positions, const int32_t *slot_mapping,
                               const int32_t *row_seq, const int32_t *context_lens, const int32_t *block_tables,
                               int max_blocks, int max_context, int N, void *hidden_out, const void *head_w, int vocab,
-                              void *logits_out, qtts_stream_t stream) {
+                              void *logits_out, qtts_stream_t stream, const int64_t *x_ids = nullptr, int x_id_rows = 0,
+                              const void *qkv0_rows = nullptr) {
     QCHECK(m, "model_forward: null model");
+    // x_ids: x is a table of x_id_rows rows and row r of the step is x[x_ids[r]] (read in place by layer 0's qkv GEMM
+    // and o_proj residual); qkv0_rows: a table of the same rows after layer 0's input norm and qkv GEMM, which then
+    // is not launched
+    QCHECK(!x_ids || (x_id_rows > 0 && N <= 16 && !row_seq), "model_forward: gathered input rows are for decode steps of up to 16 rows");
+    QCHECK(!qkv0_rows || x_ids, "model_forward: a layer-0 qkv table needs row ids");
     if (!m->final_norm || !m->cosT || !m->kv || !m->ws) QFAIL(QTTS_ESTATE, "model_forward: model not fully configured");
     for (const LayerW &L : m->layers)
         if (!L.wqkv) QFAIL(QTTS_ESTATE, "model_forward: layer weights missing");
@@ -2507,20 +2543,25 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
             xn_ready = false;
             if ((rc = stack_linear(xn, H, L.wqkv, L.s_qkv, nullptr, 0, nullptr, 0.f, qkv, qkvw, N, qkvw, H, nullptr, 0, stream)))
                 return rc;
+        } else if (l == 0 && qkv0_rows) {
+            // layer 0's normalised, projected rows come from the table
         } else if ((rc = stack_linear(cur, H, L.wqkv, L.s_qkv, nullptr, 0, L.in_norm, m->eps, qkv, qkvw, N, qkvw, H, nullptr, 0,
-                                      stream))) return rc;
+                                      stream, nullptr, nullptr, 0, l == 0 ? x_ids : nullptr, nullptr, x_id_rows))) return rc;
+        const bool tab0 = l == 0 && qkv0_rows;
         if (decode) {
-            if ((rc = attention_decode_fused_impl(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
-                                                  positions, slot_mapping, kc, vc, block_tables, max_blocks,
+            if ((rc = attention_decode_fused_impl(tab0 ? qkv0_rows : qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT,
+                                                  m->max_pos, positions, slot_mapping, kc, vc, block_tables, max_blocks,
                                                   context_lens, max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws,
-                                                  (int *)(m->ws + W.att_cnt), (hipStream_t)stream))) return rc;
+                                                  (int *)(m->ws + W.att_cnt), (hipStream_t)stream,
+                                                  tab0 ? x_ids : nullptr, x_id_rows))) return rc;
         } else {
             if ((rc = qtts_qknorm_rope_store(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
                                              positions, slot_mapping, kc, vc, N, Hq, Hkv, stream))) return rc;
             if ((rc = qtts_paged_attention(qkv, qkvw, kc, vc, block_tables, max_blocks, row_seq, context_lens,
                                            max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws, stream))) return rc;
         }
-        if ((rc = stack_linear(attn, Hq * 128, L.wo, L.s_o, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, nullptr, 0, stream)))
+        if ((rc = stack_linear(attn, Hq * 128, L.wo, L.s_o, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, nullptr, 0, stream,
+                               nullptr, nullptr, 0, nullptr, l == 0 ? x_ids : nullptr, x_id_rows)))
             return rc;
         if (split_norm) {
             if ((rc = qtts_rmsnorm(xa, H, L.post_norm, m->eps, xn, H, N, H, stream))) return rc;
@@ -2569,6 +2610,18 @@ extern "C" int qtts_model_forward_logits(qtts_model_t *m, const void *x, const i
     QCHECK(head_w_packed && logits_out && vocab > 0 && vocab % 16 == 0, "model_forward_logits: bad head arguments");
     return model_forward_impl(m, x, positions, slot_mapping, row_seq, context_lens, block_tables, max_blocks, max_context,
                               N, hidden_out, head_w_packed, vocab, logits_out, stream);
+}
+
+extern "C" int qtts_model_forward_logits_gathered(qtts_model_t *m, const void *x_table, const void *qkv0_table,
+                                                  const int64_t *ids, int table_rows, const int64_t *positions,
+                                                  const int32_t *slot_mapping, const int32_t *context_lens,
+                                                  const int32_t *block_tables, int max_blocks, int max_context, int N,
+                                                  void *hidden_out, const void *head_w_packed, int vocab,
+                                                  void *logits_out, qtts_stream_t stream) {
+    QCHECK(head_w_packed && logits_out && vocab > 0 && vocab % 16 == 0, "model_forward_logits_gathered: bad head arguments");
+    QCHECK(x_table && ids && table_rows > 0, "model_forward_logits_gathered: null table or ids");
+    return model_forward_impl(m, x_table, positions, slot_mapping, nullptr, context_lens, block_tables, max_blocks, max_context,
+                              N, hidden_out, head_w_packed, vocab, logits_out, stream, ids, table_rows, qkv0_table);
 }
 
 // ------------------------------------------------------------------ grid barrier probe (tuning experiments only)

@@ -61,6 +61,14 @@ class PredictorModelRunner(ModelRunner):
             assert self.talker_hidden == s.hidden_size
             self.proj_w = self.proj_b = None
         Ht, h = self.talker_hidden, s.hidden_size
+        # Decode steps of a burst start from rows of a table (codec_embedding[i] of the previous token): the
+        # projection of every table row, and layer 0's input norm + qkv projection of it, depend on the weights
+        # only and are computed once here with the same GEMM launches a step would use (same bits); a step then
+        # gathers instead of projecting.  QTTS_FOLD_INPUT=0 keeps the per-step launches.
+        self.fold = os.environ.get("QTTS_FOLD_INPUT", "1") == "1" and self.decoder.weight_dtype == "bf16"
+        self.x_tables, self.qkv0_tables = [], []
+        if self.fold:
+            self._fold_tables()
         self.e_buf = torch.zeros(self.max_rows, Ht, dtype=torch.bfloat16, device=self.device)   # talker-width inputs
         self.x_buf = torch.zeros(self.max_rows, h, dtype=torch.bfloat16, device=self.device)    # after projection
         self.h_buf = torch.zeros(self.max_rows, h, dtype=torch.bfloat16, device=self.device)
@@ -92,6 +100,36 @@ class PredictorModelRunner(ModelRunner):
         self._programs: dict[int, torch.Tensor] = {}
 
     # ---- pieces ---------------------------------------------------------------------
+    def _fold_tables(self):
+        """x_tables[i] = small_to_mtp_projection(codec_embedding[i].weight) (P/models/qwen3_tts_predictor.py:58-61,
+        94-95,106); qkv0_tables[i] = layer 0's qkv_proj(input_layernorm(.)) of those rows
+        (P/models/qwen3_tts_share.py:96-99,168-169).  Sixteen rows per launch: the decode GEMM kernel itself."""
+        s, lib = self.shape, hip.lib
+        h, Ht = s.hidden_size, self.talker_hidden
+        qkvw = (s.num_heads + 2 * s.num_kv_heads) * s.head_dim
+        d = self.decoder
+        for tb in self.tables:
+            rows = tb.shape[0]
+            ids = torch.arange(rows, dtype=torch.int64, device=self.device)
+            if self.proj_w is not None:
+                xt = torch.empty(rows, h, dtype=torch.bfloat16, device=self.device)
+                for c in range(0, rows, 16):
+                    n = min(16, rows - c)
+                    hip.check(lib.qtts_linear_fused(hip.ptr(tb), Ht, hip.ptr(ids) + 8 * c, rows, hip.ptr(self.proj_w),
+                                                    hip.ptr(self.proj_b), None, 0, None, 0.0, None, 0, 0,
+                                                    hip.ptr(xt) + 2 * c * h, h, n, h, Ht, hip.stream()), "fold proj")
+            else:
+                xt = tb
+            qt = torch.empty(rows, qkvw, dtype=torch.bfloat16, device=self.device)
+            for c in range(0, rows, 16):
+                n = min(16, rows - c)
+                hip.check(lib.qtts_linear_fused(hip.ptr(xt) + 2 * c * h, h, None, 0, hip.ptr(d.layer0_wqkv), None, None, 0,
+                                                hip.ptr(d.layer0_in_norm), s.rms_eps, None, 0, 0,
+                                                hip.ptr(qt) + 2 * c * qkvw, qkvw, n, qkvw, h, hip.stream()), "fold qkv0")
+            self.x_tables.append(xt)
+            self.qkv0_tables.append(qt)
+        torch.cuda.synchronize()
+
     def _project(self, n_rows: int):
         """small_to_mtp_projection (P/models/qwen3_tts_predictor.py:58-61,106)."""
         if self.proj_w is None:
@@ -239,6 +277,16 @@ class PredictorModelRunner(ModelRunner):
         for step in range(1, self.n_gen):
             tb = self.tables[step - 1]
             prev = hip.ptr(self.burst_tokens) + 8 * (step - 1) * bs
+            if self.fold and bs <= 16:               # one 16-row tile: the decode kernels (larger batches project per step)
+                xt, qt = self.x_tables[step - 1], self.qkv0_tables[step - 1]
+                hip.check(hip.lib.qtts_model_forward_logits_gathered(
+                    self.decoder._h, hip.ptr(xt), hip.ptr(qt), prev, xt.shape[0], hip.ptr(st.d("positions")[off:off + bs]),
+                    hip.ptr(st.d("slots")[off:off + bs]), hip.ptr(st.d("ctx")[off:off + bs]), hip.ptr(tables), mb, step + 2,
+                    bs, hip.ptr(self.h_buf), hip.ptr(self.heads[step]), self.vocab, hip.ptr(self.logits), stream()),
+                    "model_forward_logits_gathered")
+                pick(step)
+                off += bs
+                continue
             if self.proj_w is not None:
                 # codec_embedding[step-1](token) -> small_to_mtp_projection in one launch (gathered GEMM rows)
                 hip.check(hip.lib.qtts_linear_fused(hip.ptr(tb), Ht, prev, tb.shape[0], hip.ptr(self.proj_w),

@@ -160,6 +160,56 @@ def test_resident_burst_equals_staged_burst_at_model_shapes(wgs, group, monkeypa
     assert same >= 7, (results["1"], results["0"])
 
 
+def test_folded_input_tables_give_the_same_bits(monkeypatch, tmp_path):
+    """1.7B predictor shapes, 8 sequences: a burst whose decode steps read the projected embedding rows and layer 0's
+    qkv rows from tables built at load (QTTS_FOLD_INPUT=1, the default) returns bit for bit what the burst that
+    gathers, projects and runs layer 0's qkv GEMM every step returns: ids, last logits and last hidden state.
+    (P/models/qwen3_tts_predictor.py:87-99,106; P/models/qwen3_tts_share.py:96-99)"""
+    import json, os
+    from nano_qwen3tts_vllm.llm import PredictorLLM
+    cfg = synthetic.make_config("1.7B")
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    pw = {}
+    for k, shp in synthetic.checkpoint_shapes(cfg).items():
+        if not k.startswith("talker.code_predictor."):
+            continue
+        if k.endswith("norm.weight") or k.endswith("layernorm.weight"):
+            w = (1.0 + 0.1 * torch.randn(shp, generator=gen, device="cuda")).to(torch.bfloat16)
+        else:
+            std = 0.05 if "codec_embedding" in k else (0.8 if "lm_head" in k else 0.02)
+            w = (torch.randn(shp, generator=gen, device="cuda") * std).to(torch.bfloat16)
+        pw[k[len("talker.code_predictor."):]] = w
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(4)
+    pin = (torch.randn(8, 2, cfg["talker_config"]["hidden_size"], generator=gen) * 0.5).bfloat16()
+    res = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("QTTS_FOLD_INPUT", fold)
+        monkeypatch.setenv("QTTS_PREDICTOR_RESIDENT", "0")
+        llm = PredictorLLM(str(tmp_path), weights=pw, num_kvcache_blocks=8, max_num_seqs=8, max_num_batched_tokens=1024)
+        mr = llm.model_runner
+        assert mr.fold == (fold == "1")
+        if mr.fold:
+            # a table row is what the per-step launch computes for that id
+            from nano_qwen3tts_vllm import hip
+            ids = torch.tensor([0, 5, 2047, 1000, 17, 17, 3, 999], dtype=torch.int64, device="cuda")
+            tb, Ht, h = mr.tables[3], mr.talker_hidden, mr.shape.hidden_size
+            out = torch.empty(8, h, dtype=torch.bfloat16, device="cuda")
+            hip.check(hip.lib.qtts_linear_fused(hip.ptr(tb), Ht, hip.ptr(ids), tb.shape[0], hip.ptr(mr.proj_w),
+                                                hip.ptr(mr.proj_b), None, 0, None, 0.0, None, 0, 0, hip.ptr(out), h, 8, h, Ht,
+                                                hip.stream()), "gather+proj")
+            torch.cuda.synchronize()
+            assert torch.equal(out, mr.x_tables[3][ids])
+        for i in range(8):
+            llm.add_request([pin[i].unsqueeze(0)], greedy_sp(17), request_id=f"p{i}")
+        outs, _ = llm.step()
+        torch.cuda.synchronize()
+        res[fold] = ({rid: toks for rid, _sid, toks in outs}, mr.logits[:8].clone(), mr.h_buf[:8].clone())
+        llm.exit()
+    assert res["1"][0] == res["0"][0]
+    assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
+
+
 def test_frame_loop_ids_match_reference_fixture(setup):
     """Talker -> predictor burst -> fp32 glue -> talker, 2 streams x 6 frames, greedy."""
     from nano_qwen3tts_vllm.llm import PredictorLLM, TalkerLLM
