@@ -42,10 +42,13 @@ def make_weights(cfg, device, seed=1234):
     return synthetic.split_state_dict(sd)
 
 
-def algorithmic_bytes_per_frame(cfg, B, mean_ctx, weights="bf16"):
+def algorithmic_bytes_per_frame(cfg, B, mean_ctx, weights="bf16", folded=False):
     """Bytes one frame must move: every talker weight once, the predictor's per-step weights
     15 times, plus the KV rows attention reads (bf16).  With fp8 weights the layers' projection
-    matrices count one byte per element (+ 4 bytes of scale per row, neglected)."""
+    matrices count one byte per element (+ 4 bytes of scale per row, neglected).  folded: the
+    predictor's 14 decode steps read their projected input rows and layer 0's qkv rows from tables
+    built at load, so the projection matrix and layer 0's q/k/v matrices are not streamed in
+    those steps (the B table rows read instead are counted)."""
     from nano_qwen3tts_vllm.utils import synthetic
     shapes = synthetic.checkpoint_shapes(cfg)
     numel = lambda k: int(torch.tensor(shapes[k]).prod())
@@ -66,7 +69,15 @@ def algorithmic_bytes_per_frame(cfg, B, mean_ctx, weights="bf16"):
         proj = lambda pre: sum(numel(k) for k in shapes if k.startswith(pre) and "_proj.weight" in k)
         tproj, pproj = proj("talker.model.layers."), proj("talker.code_predictor.model.layers.")
         return (2 * talker - tproj) + n_gen * (2 * pred_step - pproj) + B * mean_ctx * kv_t + B * pred_ctx * kv_p
-    return 2 * talker + 2 * n_gen * pred_step + B * mean_ctx * kv_t + B * pred_ctx * kv_p
+    saved = 0
+    if folded:
+        l0 = "talker.code_predictor.model.layers.0."
+        skipped = sum(numel(l0 + f"self_attn.{n}_proj.weight") for n in "qkv") + numel(l0 + "input_layernorm.weight")
+        qkvw = (p["num_attention_heads"] + 2 * p["num_key_value_heads"]) * p["head_dim"]
+        if "talker.code_predictor.small_to_mtp_projection.weight" in shapes:
+            skipped += numel("talker.code_predictor.small_to_mtp_projection.weight")
+        saved = (n_gen - 1) * (2 * skipped - 2 * B * (qkvw + p["hidden_size"]))
+    return 2 * talker + 2 * n_gen * pred_step + B * mean_ctx * kv_t + B * pred_ctx * kv_p - saved
 
 
 def time_dominant_kernel(fe, B, rounds=20):
@@ -253,7 +264,8 @@ def main():
         tokens = whole_job_tokens(B, args.steps, world)
         value = tokens / elapsed
         mean_ctx = sum(prompt_lens) / B + 1 + args.warmup + 1 + args.steps / 2
-        bytes_frame = algorithmic_bytes_per_frame(cfg, B, mean_ctx, args.weights)
+        folded = bool(getattr(fe.pr, "fold", False)) and B <= 16
+        bytes_frame = algorithmic_bytes_per_frame(cfg, B, mean_ctx, args.weights, folded)
         ksec, kbytes = time_dominant_kernel(fe, B)
         out = {
             "metric": "codec tokens/sec at 8 concurrent streams per GPU (RTF alongside), Qwen3-TTS-1.7B",

@@ -283,6 +283,16 @@ int qtts_model_forward_logits_gathered(qtts_model_t *m, const void *x_table, con
                                        const int32_t *block_tables, int max_blocks, int max_context, int N,
                                        void *hidden_out, const void *head_w_packed, int vocab,
                                        void *logits_out, qtts_stream_t stream);
+/* The 2-position prompt of N/2 fresh sequences (the code predictor's burst starts with [talker hidden, first
+ * codebook embedding] per sequence, P/workers/predictor_worker.py:128-134 -> predictor_model_runner.py:134-157 in
+ * prefill mode): rows (2i, 2i+1) of x [N,hidden] are positions[2i], positions[2i+1] of sequence i, contexts 1
+ * and 2, N even and <= 16.  q/k norm, RoPE, KV store (slot_mapping, -1 = skip) and both rows' attention are one
+ * launch per layer.  logits_out [N/2, vocab] and hidden_out [N/2, hidden] belong to the second row of each pair
+ * (the last position, talker_mode_runner.py:107-110 / compute_logits). */
+int qtts_model_forward_logits_pairs(qtts_model_t *m, const void *x, const int64_t *positions,
+                                    const int32_t *slot_mapping, int N, void *hidden_out,
+                                    const void *head_w_packed, int vocab, void *logits_out,
+                                    qtts_stream_t stream);
 
 /* ---------------------------------------------------------------- resident burst
  * The code predictor's whole burst for up to 8 sequences — the 2-position prefill and

@@ -1919,6 +1919,112 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
     return QTTS_OK;
 }
 
+// ---- the 2-position prompt of a fresh sequence (the code predictor's burst starts with one per sequence): rows
+// (2i, 2i+1) are positions (p, p+1) of sequence i, contexts 1 and 2.  q/k norm + RoPE + KV store + attention of
+// both rows in one launch, one (sequence, kv head) per workgroup, sixteen lanes per query head.  Row 2i attends
+// to itself only (weight exactly 1: its output is its V row); row 2i+1 to both, the first row's K taken from
+// registers, not from the cache it was just written to.
+template <int G>
+__global__ __launch_bounds__(64) void attn_pair_kernel(const bf16_t *__restrict__ qkv, int ld,
+                                                       const int64_t *__restrict__ positions,
+                                                       const int32_t *__restrict__ slots, const bf16_t *__restrict__ qw,
+                                                       const bf16_t *__restrict__ kw, const bf16_t *__restrict__ cosT,
+                                                       const bf16_t *__restrict__ sinT, int max_pos, float eps,
+                                                       bf16_t *__restrict__ kc, bf16_t *__restrict__ vc, float scale,
+                                                       bf16_t *__restrict__ out, int ldo, int Hq, int Hkv) {
+    const int seq = blockIdx.x, kvh = blockIdx.y;
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    if (grp >= G) return;
+    // every request of the launch goes out before the first use
+    long pos[2];
+    int slot[2];
+    Frag kraw[2], vb[2], fq, qwv, kwv;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int row = 2 * seq + rr;
+        const bf16_t *rowp = qkv + (size_t)row * ld;
+        pos[rr] = positions[row];
+        slot[rr] = (slots ? slots : reinterpret_cast<const int32_t *>(positions))[row];
+        kraw[rr].u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(Hq + kvh) * 128 + 8 * l16);
+        vb[rr].u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(Hq + Hkv + kvh) * 128 + 8 * l16);
+    }
+    fq.u = *reinterpret_cast<const uint4 *>(qkv + (size_t)(2 * seq + 1) * ld + (size_t)(kvh * G + grp) * 128 + 8 * l16);
+    qwv.u = *reinterpret_cast<const uint4 *>(qw + 8 * l16);
+    kwv.u = *reinterpret_cast<const uint4 *>(kw + 8 * l16);
+    Frag cv[2], sv[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const long p = pos[rr] < 0 ? 0 : (pos[rr] >= max_pos ? max_pos - 1 : pos[rr]);
+        cv[rr].u = *reinterpret_cast<const uint4 *>(cosT + p * 64 + ((8 * l16) & 63));
+        sv[rr].u = *reinterpret_cast<const uint4 *>(sinT + p * 64 + ((8 * l16) & 63));
+    }
+    Frag kb[2];
+    float x[8], o8[8];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = bf2f(kraw[rr].h[j]);
+        norm_rope8(x, kwv, cv[rr], sv[rr], eps, l16, o8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kb[rr].h[j] = f2bf(o8[j]);
+        const int sl = slots ? slot[rr] : -1;
+        if (sl >= 0 && grp == 0) {
+            const size_t off = ((size_t)sl * Hkv + kvh) * 128 + 8 * l16;
+            *reinterpret_cast<uint4 *>(kc + off) = kb[rr].u;
+            *reinterpret_cast<uint4 *>(vc + off) = vb[rr].u;
+        }
+    }
+    float q1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = bf2f(fq.h[j]);
+    norm_rope8(x, qwv, cv[1], sv[1], eps, l16, q1);
+    const int hq = kvh * G + grp;
+    *reinterpret_cast<uint4 *>(out + (size_t)(2 * seq) * ldo + (size_t)hq * 128 + 8 * l16) = vb[0].u;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s0 += q1[j] * bf2f(kb[0].h[j]);
+        s1 += q1[j] * bf2f(kb[1].h[j]);
+    }
+    s0 = row16_sum(s0) * scale;
+    s1 = row16_sum(s1) * scale;
+    const float mx = fmaxf(s0, s1);
+    const float p0 = __expf(s0 - mx), p1 = __expf(s1 - mx);
+    const float L = p0 + p1;
+    Frag o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float acc = p0 * bf2f(vb[0].h[j]);
+        acc += p1 * bf2f(vb[1].h[j]);
+        o.h[j] = f2bf(acc / L);
+    }
+    *reinterpret_cast<uint4 *>(out + (size_t)(2 * seq + 1) * ldo + (size_t)hq * 128 + 8 * l16) = o.u;
+}
+
+static int attention_pairs_impl(const void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w, float eps,
+                                const void *rope_cos, const void *rope_sin, int max_pos, const int64_t *positions,
+                                const int32_t *slot_mapping, void *k_cache, void *v_cache, float scale, void *out, int ldo,
+                                int N, int Hq, int Hkv, hipStream_t s) {
+    QCHECK(qkv && q_norm_w && k_norm_w && rope_cos && rope_sin && positions && k_cache && v_cache && out,
+           "attention_pairs: null pointer");
+    QCHECK(N > 0 && N % 2 == 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && ldqkv % 8 == 0 && ldqkv >= (Hq + 2 * Hkv) * 128 &&
+               ldo >= Hq * 128 && max_pos > 0, "attention_pairs: bad shape");
+    dim3 grid(N / 2, Hkv);
+#define QPAIR(G_) hipLaunchKernelGGL((attn_pair_kernel<G_>), grid, dim3(64), 0, s, (const bf16_t *)qkv, ldqkv, positions, \
+                                     slot_mapping, (const bf16_t *)q_norm_w, (const bf16_t *)k_norm_w, (const bf16_t *)rope_cos, \
+                                     (const bf16_t *)rope_sin, max_pos, eps, (bf16_t *)k_cache, (bf16_t *)v_cache, scale, \
+                                     (bf16_t *)out, ldo, Hq, Hkv)
+    switch (Hq / Hkv) {
+        case 1: QPAIR(1); break;
+        case 2: QPAIR(2); break;
+        case 4: QPAIR(4); break;
+        default: QFAIL(QTTS_EINVAL, "attention_pairs: unsupported q/kv head ratio %d", Hq / Hkv);
+    }
+#undef QPAIR
+    QLAUNCH();
+    return QTTS_OK;
+}
+
 extern "C" size_t qtts_attn_decode_workspace_bytes(int B, int Hq, int Hkv, int max_context) {
     if (B <= 0 || Hq <= 0 || Hkv <= 0 || max_context <= 0) return 0;
     return attn2_partial_bytes(B, Hq, max_context) + (((size_t)B * Hkv * sizeof(int) + 255) & ~(size_t)255);
@@ -2500,7 +2606,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
                               const int32_t *row_seq, const int32_t *context_lens, const int32_t *block_tables,
                               int max_blocks, int max_context, int N, void *hidden_out, const void *head_w, int vocab,
                               void *logits_out, qtts_stream_t stream, const int64_t *x_ids = nullptr, int x_id_rows = 0,
-                              const void *qkv0_rows = nullptr) {
+                              const void *qkv0_rows = nullptr, bool pairs = false) {
     QCHECK(m, "model_forward: null model");
     // x_ids: x is a table of x_id_rows rows and row r of the step is x[x_ids[r]] (read in place by layer 0's qkv GEMM
     // and o_proj residual); qkv0_rows: a table of the same rows after layer 0's input norm and qkv GEMM, which then
@@ -2510,10 +2616,12 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     if (!m->final_norm || !m->cosT || !m->kv || !m->ws) QFAIL(QTTS_ESTATE, "model_forward: model not fully configured");
     for (const LayerW &L : m->layers)
         if (!L.wqkv) QFAIL(QTTS_ESTATE, "model_forward: layer weights missing");
-    QCHECK(x && positions && context_lens && block_tables && hidden_out, "model_forward: null pointer");
+    QCHECK(x && positions && hidden_out && (pairs || (context_lens && block_tables)), "model_forward: null pointer");
+    // pairs: rows (2i, 2i+1) are the two positions of a fresh sequence i; the head (required) runs on the second rows
+    QCHECK(!pairs || (N % 2 == 0 && N <= 16 && !row_seq && !x_ids && head_w), "model_forward: bad 2-position prompt arguments");
     QCHECK(N > 0 && N <= m->ws_rows, "model_forward: N=%d exceeds workspace rows %d", N, m->ws_rows);
     QCHECK(max_context > 0 && max_context <= m->ws_ctx, "model_forward: max_context=%d exceeds workspace %d", max_context, m->ws_ctx);
-    QCHECK(max_blocks > 0 && max_context <= max_blocks * QTTS_KV_BLOCK, "model_forward: max_context exceeds block table");
+    QCHECK(pairs || (max_blocks > 0 && max_context <= max_blocks * QTTS_KV_BLOCK), "model_forward: max_context exceeds block table");
     const WsLayout W = ws_layout(m, m->ws_rows, m->ws_ctx);
     bf16_t *qkv = (bf16_t *)(m->ws + W.qkv);
     bf16_t *attn = (bf16_t *)(m->ws + W.attn);
@@ -2548,7 +2656,11 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         } else if ((rc = stack_linear(cur, H, L.wqkv, L.s_qkv, nullptr, 0, L.in_norm, m->eps, qkv, qkvw, N, qkvw, H, nullptr, 0,
                                       stream, nullptr, nullptr, 0, l == 0 ? x_ids : nullptr, nullptr, x_id_rows))) return rc;
         const bool tab0 = l == 0 && qkv0_rows;
-        if (decode) {
+        if (pairs) {
+            if ((rc = attention_pairs_impl(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos, positions,
+                                           slot_mapping, kc, vc, scale, attn, Hq * 128, N, Hq, Hkv, (hipStream_t)stream)))
+                return rc;
+        } else if (decode) {
             if ((rc = attention_decode_fused_impl(tab0 ? qkv0_rows : qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT,
                                                   m->max_pos, positions, slot_mapping, kc, vc, block_tables, max_blocks,
                                                   context_lens, max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws,
@@ -2586,6 +2698,9 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
             return qtts_linear_fused(hidden_out, H, nullptr, 0, head_w, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, 0,
                                      logits_out, vocab, N, vocab, H, stream);
         }
+        if (pairs)      // the second row of every pair: a strided view; hidden_out gets those N/2 rows
+            return qtts_linear_fused(cur + H, 2 * H, nullptr, 0, head_w, nullptr, nullptr, 0, m->final_norm, m->eps, hidden_out, H,
+                                     0, logits_out, vocab, N / 2, vocab, H, stream);
         // final RMSNorm folded into the head GEMM's prologue; the normalised rows are the returned hidden state
         if ((rc = qtts_linear_fused(cur, H, nullptr, 0, head_w, nullptr, nullptr, 0, m->final_norm, m->eps, hidden_out, H, 0,
                                     logits_out, vocab, N, vocab, H, stream))) return rc;
@@ -2622,6 +2737,15 @@ extern "C" int qtts_model_forward_logits_gathered(qtts_model_t *m, const void *x
     QCHECK(x_table && ids && table_rows > 0, "model_forward_logits_gathered: null table or ids");
     return model_forward_impl(m, x_table, positions, slot_mapping, nullptr, context_lens, block_tables, max_blocks, max_context,
                               N, hidden_out, head_w_packed, vocab, logits_out, stream, ids, table_rows, qkv0_table);
+}
+
+extern "C" int qtts_model_forward_logits_pairs(qtts_model_t *m, const void *x, const int64_t *positions,
+                                               const int32_t *slot_mapping, int N, void *hidden_out,
+                                               const void *head_w_packed, int vocab, void *logits_out,
+                                               qtts_stream_t stream) {
+    QCHECK(head_w_packed && logits_out && vocab > 0 && vocab % 16 == 0, "model_forward_logits_pairs: bad head arguments");
+    return model_forward_impl(m, x, positions, slot_mapping, nullptr, nullptr, nullptr, 0, 2, N, hidden_out, head_w_packed,
+                              vocab, logits_out, stream, nullptr, 0, nullptr, true);
 }
 
 // ------------------------------------------------------------------ grid barrier probe (tuning experiments only)

@@ -66,6 +66,7 @@ class PredictorModelRunner(ModelRunner):
         # only and are computed once here with the same GEMM launches a step would use (same bits); a step then
         # gathers instead of projecting.  QTTS_FOLD_INPUT=0 keeps the per-step launches.
         self.fold = os.environ.get("QTTS_FOLD_INPUT", "1") == "1" and self.decoder.weight_dtype == "bf16"
+        self.pair_prefill = os.environ.get("QTTS_PAIR_PREFILL", "1") == "1"   # 0: the general prompt path
         self.x_tables, self.qkv0_tables = [], []
         if self.fold:
             self._fold_tables()
@@ -267,11 +268,18 @@ class PredictorModelRunner(ModelRunner):
         # prefill: 2*bs rows
         n0 = 2 * bs
         x = self._project(n0)
-        self.decoder.forward(x, st.d("positions")[:n0], st.d("slots")[:n0], st.d("ctx")[:n0], tables, 2,
-                             row_seq=st.d("row_seq")[:n0], out=self.h_buf[:n0])
-        # last position of each sequence = odd rows: a strided view, no gather needed
-        hip.check(hip.lib.qtts_linear(hip.ptr(self.h_buf) + 2 * h, 2 * h, hip.ptr(self.heads[0]), None, None, 0, None,
-                                      0.0, hip.ptr(self.logits), self.vocab, bs, self.vocab, h, stream()), "head0")
+        if n0 <= 16 and self.pair_prefill:
+            # one attention launch per layer for both positions, final norm inside the head GEMM (second rows only)
+            hip.check(hip.lib.qtts_model_forward_logits_pairs(self.decoder._h, hip.ptr(x), hip.ptr(st.d("positions")),
+                                                              hip.ptr(st.d("slots")), n0, hip.ptr(self.h_buf),
+                                                              hip.ptr(self.heads[0]), self.vocab, hip.ptr(self.logits),
+                                                              stream()), "model_forward_logits_pairs")
+        else:
+            self.decoder.forward(x, st.d("positions")[:n0], st.d("slots")[:n0], st.d("ctx")[:n0], tables, 2,
+                                 row_seq=st.d("row_seq")[:n0], out=self.h_buf[:n0])
+            # last position of each sequence = odd rows: a strided view, no gather needed
+            hip.check(hip.lib.qtts_linear(hip.ptr(self.h_buf) + 2 * h, 2 * h, hip.ptr(self.heads[0]), None, None, 0, None,
+                                          0.0, hip.ptr(self.logits), self.vocab, bs, self.vocab, h, stream()), "head0")
         pick(0)
         off = n0
         for step in range(1, self.n_gen):

@@ -34,6 +34,7 @@ _SIGS = {
     "qtts_attention_decode_fused": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _f, _p, _i, _i,
                                          _i, _i, _p, _p]),
     "qtts_model_forward_logits": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
+    "qtts_model_forward_logits_pairs": (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _p, _p]),
     "qtts_model_forward_logits_gathered": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "qtts_linear_workspace_bytes": (_sz, [_i, _i, _i]),
     "qtts_linear_ws": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _sz, _p]),

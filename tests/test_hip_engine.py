@@ -210,6 +210,43 @@ def test_folded_input_tables_give_the_same_bits(monkeypatch, tmp_path):
     assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
 
 
+def test_pair_prompt_launch_agrees_with_the_general_prompt_path(monkeypatch, tmp_path):
+    """The burst's 2-position prompt through qtts_model_forward_logits_pairs (one attention launch per layer) against
+    the general prompt path (q/k-norm + store launch, paged attention launch, separate final norm): the same
+    arithmetic up to the softmax's operation order, so the first logits agree within bf16 rounding and the ids of
+    well separated logits are the same.  (P/engine/model_runner/predictor_model_runner.py:134-157)"""
+    import json, os
+    from nano_qwen3tts_vllm.llm import PredictorLLM
+    cfg = synthetic.make_config("1.7B")
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    pw = {}
+    for k, shp in synthetic.checkpoint_shapes(cfg).items():
+        if not k.startswith("talker.code_predictor."):
+            continue
+        if k.endswith("norm.weight") or k.endswith("layernorm.weight"):
+            w = (1.0 + 0.1 * torch.randn(shp, generator=gen, device="cuda")).to(torch.bfloat16)
+        else:
+            std = 0.05 if "codec_embedding" in k else (0.8 if "lm_head" in k else 0.02)
+            w = (torch.randn(shp, generator=gen, device="cuda") * std).to(torch.bfloat16)
+        pw[k[len("talker.code_predictor."):]] = w
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(6)
+    pin = (torch.randn(8, 2, cfg["talker_config"]["hidden_size"], generator=gen) * 0.5).bfloat16()
+    res = {}
+    for pair in ("1", "0"):
+        monkeypatch.setenv("QTTS_PAIR_PREFILL", pair)
+        monkeypatch.setenv("QTTS_PREDICTOR_RESIDENT", "0")
+        llm = PredictorLLM(str(tmp_path), weights=pw, num_kvcache_blocks=8, max_num_seqs=8, max_num_batched_tokens=1024)
+        for i in range(8):
+            llm.add_request([pin[i].unsqueeze(0)], greedy_sp(17), request_id=f"p{i}")
+        outs, _ = llm.step()
+        torch.cuda.synchronize()
+        res[pair] = {rid: toks for rid, _sid, toks in outs}
+        llm.exit()
+    same = sum(res["1"][f"p{i}"] == res["0"][f"p{i}"] for i in range(8))
+    assert same >= 7, (res["1"], res["0"])
+
+
 def test_frame_loop_ids_match_reference_fixture(setup):
     """Talker -> predictor burst -> fp32 glue -> talker, 2 streams x 6 frames, greedy."""
     from nano_qwen3tts_vllm.llm import PredictorLLM, TalkerLLM
