@@ -221,6 +221,11 @@ def main():
     greedy_t = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
     greedy_p = SamplingParams(temperature=0.9, max_tokens=17, do_sample=False)
     lens = [16, 48, 128, 200]
+    # a stream's prompt + frames must fit the model's 1024 positions: very long runs get shorter prompts
+    room = 1024 - (n_frames + 4)
+    if room < 8:
+        raise SystemExit(f"--steps + --warmup = {args.steps + args.warmup} frames do not fit 1024 positions per stream; use at most 1000")
+    lens = [min(L, room) for L in lens]
     g = torch.Generator().manual_seed(1000 + rank)
     # one warm-up request per prompt-kernel family (the reference's server fires warm-up requests too, E/server.py:276)
     for L in (16, 200):

@@ -240,7 +240,8 @@ struct LinArgs {
     const bf16_t *next_nw = nullptr; bf16_t *next_xn = nullptr; int ldnn = 0;   // K-split prompt GEMM only: also RMSNorm(out) * next_nw
     const float *wscale = nullptr;   // non-null: wp holds fp8 (e4m3) weights, two k-steps per 16-byte fragment; scale per packed row
     const int64_t *res_ids = nullptr; int res_id_rows = 0;   // non-null: residual row m = res[res_ids[m]] (decode GEMM only)
-    int dbg;      // bit0: tuning experiment (every tile reads weight tile 0); bits 8+: row-tile count of a prefill launch
+    int dbg;      // bit0: tuning experiment (every tile reads weight tile 0); bit3: `ids` select the residual rows, not the
+                  // x rows; bits 4-5: log2 of the workgroups per tile; bits 8+: row-tile count of a prefill launch
 };
 
 // 16 fp8 (e4m3, OCP) values -> two bf16 fragments, exactly (every e4m3 value is a bf16 value).  Bytes 0..7 belong
@@ -274,7 +275,6 @@ struct LinTail {
     bf16_t *out; int ldo;
     long long *trace;     // tuning experiments only (null in production): 4 timestamps per workgroup
     const float *wscale;  // fp8 weights: one power-of-two scale per packed weight row
-    const int64_t *res_ids; int res_id_rows;   // residual rows gathered from a table (null: row m)
 };
 #define QTTS_TRACE(slot) do { if (tl.trace && threadIdx.x == 0) tl.trace[(size_t)blockIdx.x * 4 + (slot)] = wall_clock64(); } while (0)
 
@@ -329,18 +329,19 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     size_t xrow = 0;
     {
         long rid = mvalid ? m : 0;
-        if (p.ids) {
+        if (p.ids && !(p.dbg & 8)) {
             rid = p.ids[rid];
             rid = rid < 0 ? 0 : (rid >= p.id_rows ? p.id_rows - 1 : rid);
         }
         xrow = (size_t)rid * p.ldx;
     }
-    size_t rrow = (size_t)m * p.ldr;
-    if (EPI == 0 && tl.res_ids) {
-        long rid = tl.res_ids[mvalid ? m : 0];
-        rid = rid < 0 ? 0 : (rid >= tl.res_id_rows ? tl.res_id_rows - 1 : rid);
-        rrow = (size_t)rid * p.ldr;
-    }
+    // Residual rows gathered from a table (bit 3 of dbg: `ids` are theirs): the id is requested here, in front of
+    // everything else and without a branch (a launch without such ids reads 8 bytes of x instead), and first used
+    // when the residual words are requested, behind the weight requests.  Everything this depends on arrives in
+    // SGPRs with the wave.
+    long rres = 0;
+    if (EPI == 0)
+        rres = *(((p.dbg & 8) && p.ids) ? p.ids + (mvalid ? m : 0) : reinterpret_cast<const int64_t *>(p.x));
     const bf16_t *xp = p.x + xrow + 32 * ks0 + 8 * g;
 #pragma unroll
     for (int i = 0; i < KSW; ++i) {
@@ -392,6 +393,11 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         }
     }
 
+    size_t rrow = (size_t)m * p.ldr;
+    if (EPI == 0 && (p.dbg & 8)) {
+        rres = rres < 0 ? 0 : (rres >= p.id_rows ? p.id_rows - 1 : rres);
+        rrow = (size_t)rres * p.ldr;
+    }
     float *normred = reinterpret_cast<float *>(smem4 + (size_t)2 * NW * 64);
     if (PRO == 1) {
         float ss = 0.f;
@@ -793,7 +799,6 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
         ++g_trace_launch;
     }
     tl.wscale = a.wscale;
-    tl.res_ids = a.res_ids; tl.res_id_rows = a.res_id_rows;
     if constexpr (KSW % 2 == 0 && PRO != 2) {
         if (a.wscale) {
             hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI, SUB, true>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids,
@@ -899,7 +904,7 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     QCHECK(pro != 1 || a.nw, "linear: norm prologue without weight");
     QCHECK(!a.xnorm_out || (a.ldxn % 8 == 0 && a.ldxn >= a.K), "linear: bad xnorm_out stride");
     // from three row tiles on; with two, single-tile workgroups are faster (a frame at 32 streams: 4.79 against 5.01 ms)
-    QCHECK(!a.res_ids || (a.M <= 16 && a.res && a.res_id_rows > 0), "linear: gathered residual rows need M <= 16 and a residual table");
+    QCHECK(!a.res_ids || (a.M <= 16 && a.res && a.res_id_rows > 0 && !a.ids && !a.bias), "linear: gathered residual rows need M <= 16, a residual table and plain x rows");
     if (a.M > g_rows_min && pro == 0 && !a.ids && !(g_dbg_linear & 2) && launch_linear_rows(a, silu_pairs, scratch, scratch_bytes, s)) {
         QLAUNCH();
         return QTTS_OK;
@@ -931,7 +936,10 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     const bool db = tpw > 1;                              // tile loop with a register double buffer
     if (silu_pairs) QCHECK(KSW <= 12, "linear: the SwiGLU epilogue needs K <= 3072 (K=%d)", a.K);
     a.tiles_per_wg = tpw;
-    a.dbg = g_dbg_linear;
+    a.dbg = g_dbg_linear & ~8;
+    if (a.res_ids) {                                       // the kernel's id arguments carry the residual's row ids
+        a.ids = a.res_ids; a.id_rows = a.res_id_rows; a.dbg |= 8;
+    }
     int gx = (ntiles + tpw - 1) / tpw;
     const int gy = (a.M + 15) / 16;
     int ssh = 0;
