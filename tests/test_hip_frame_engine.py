@@ -142,3 +142,38 @@ def test_stream_counts_between_the_power_of_two_buckets(tmp_path, max_streams):
         solo.remove_stream(sid)
         assert np.array_equal(got[i], want), i
     solo.exit()
+
+
+def test_full_size_batch_invariance_and_graph_equals_eager(tmp_path):
+    """Qwen3-TTS-1.7B shapes (28 + 5 layers, the bench's random-init weights), 8 streams, 3 frames.  Two properties
+    that hold at any size because every row of a step is computed independently of the others and a graph replays
+    the launches it captured: (1) the frame graphs return exactly the ids of eager launches; (2) a stream run alone
+    returns exactly the ids it gets inside a batch of 8 (equal prompt lengths, so the attention split is the same)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    from nano_qwen3tts_vllm.utils import synthetic
+    cfg = synthetic.make_config("1.7B")
+    dev = torch.device("cuda")
+    tw, pw = bench.make_weights(cfg, dev)
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    H, B, NF, L = cfg["talker_config"]["hidden_size"], 8, 3, 100
+    g = torch.Generator().manual_seed(77)
+    prompts = [(torch.randn(L, H, generator=g) * 0.5) for _ in range(B)]
+    texts = [(torch.randn(NF + 2, H, generator=g) * 0.1) for _ in range(B)]
+
+    def run(which, eager):
+        fe = FrameEngine(str(tmp_path), max_streams=B, max_text_frames=NF + 2, talker_weights=tw, predictor_weights=pw,
+                         enforce_eager=eager, num_kvcache_blocks=4 * B, max_num_batched_tokens=4096, codec_eos=None)
+        for i in which:
+            fe.add_stream(prompts[i].to(dev), texts[i].to(dev), max_frames=NF + 1, talker_sampling=greedy(1),
+                          predictor_sampling=greedy(17, 0.9))
+        ids = fe.run_frames(NF).permute(1, 0, 2)[:len(which)].clone()
+        fe.exit()
+        return ids
+
+    batch = run(range(B), False)
+    assert batch.shape == (B, NF, 16)
+    assert torch.equal(batch, run(range(B), True)), "graph replay differs from eager launches"
+    assert torch.equal(batch[3:4], run([3], False)), "a stream's ids depend on its batch"
