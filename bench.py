@@ -245,10 +245,14 @@ def main():
         fe.add_stream(prompt, text, max_frames=n_frames + 2, talker_sampling=greedy_t, predictor_sampling=greedy_p)
         torch.cuda.synchronize()
         first_frame_ms.append((time.perf_counter() - t0) * 1e3)      # prefill -> first talker id + hidden
-    # one frame with everything admitted: the rest of a stream's first 16-code frame
+    # one frame with everything admitted, through the serving call (FrameEngine.step returns when the frame's 16 codes
+    # are on the host; the talker step that starts the next frame is still running then): the rest of a stream's
+    # first 16-code frame
     t0 = time.perf_counter()
-    fe.run_frames(1)
+    first = fe.step()
     frame0_ms = (time.perf_counter() - t0) * 1e3
+    assert len(first) == B and all(len(c) == 16 for c in first.values())
+    torch.cuda.synchronize()
 
     fe.run_frames(args.warmup)
 

@@ -177,14 +177,17 @@ class FrameEngine:
         n_gen, B = pr.n_gen, 256
         n0 = 2 * bs
         pos, slot, ctx, rs = st.h("positions"), st.h("slots"), st.h("ctx"), st.h("row_seq")
-        for i in range(bs):
-            rs[2 * i] = rs[2 * i + 1] = i
-            pos[2 * i], pos[2 * i + 1] = 0, 1
-            slot[2 * i], slot[2 * i + 1] = i * B, i * B + 1
-            ctx[2 * i], ctx[2 * i + 1] = 1, 2
-            for step in range(1, n_gen):
-                r = n0 + (step - 1) * bs + i
-                pos[r], slot[r], ctx[r] = step + 1, i * B + step + 1, step + 2
+        i = torch.arange(bs)
+        for k in (0, 1):                                   # rows (2i, 2i+1): the two prompt positions of sequence i
+            rs[k:n0:2] = i
+            pos[k:n0:2] = k
+            slot[k:n0:2] = i * B + k
+            ctx[k:n0:2] = k + 1
+        for step in range(1, n_gen):                       # then bs rows per decode step
+            r0 = n0 + (step - 1) * bs
+            pos[r0:r0 + bs] = step + 1
+            slot[r0:r0 + bs] = i * B + step + 1
+            ctx[r0:r0 + bs] = step + 2
         mb = pr.max_blocks_per_seq
         tab = st.h("tables")[:bs * mb].view(bs, mb)
         tab.fill_(0)
