@@ -375,10 +375,25 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     Frag a[DB ? 2 : 1][NLD];
     {
         const uint4 *wptr = p.wp + ((size_t)((p.dbg & 1) ? 0 : t_begin) * KSP + kp0) * 64 + lane;
+        if constexpr (SUB && !W8 && KSW % 2 == 0) {
+            // Two workgroups per tile (ssh == 1): a workgroup needs 8 of the tile's 16 rows, i.e. half the lanes of a
+            // k-step's 1 KiB fragment.  One full-width request serves TWO k-steps: a lane that owns its row reads
+            // its own 16 bytes of the even k-step, the other lanes read the 16 bytes of their partner (lane ^ 8, the
+            // same g, row +- 8) of the odd k-step, and a row rotate hands those to the partner afterwards.  Half
+            // the requests of the masked form, every one 64 lanes wide.  Rows the workgroup does not own hold data
+            // of other rows / k-steps: an MFMA output row depends on its own A row only, and those outputs are
+            // never stored.
+            const uint4 *wsub = p.wp + ((size_t)((p.dbg & 1) ? 0 : t_begin) * KSP + kp0 + (arow ? 0 : 1)) * 64 + (arow ? lane : lane ^ 8);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            if (arow) a[0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
-            else a[0][i].u = make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < NLD; i += 2) {
+                a[0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wsub + i * 64));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                if (arow) a[0][i].n = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(wptr + i * 64));
+                else a[0][i].u = make_uint4(0, 0, 0, 0);
+            }
         }
         if (DB) {
             // tile loop: two tiles are in flight from the start; a fragment register is refilled with the tile
@@ -461,6 +476,13 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         float4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
+            if constexpr (SUB && !W8 && KSW % 2 == 0) {
+                if (i % 2 == 0)      // the odd k-step's rows arrived in the partner lanes (row_ror:8 == lane ^ 8)
+                    a[0][i + 1].u = make_uint4(__builtin_amdgcn_update_dpp(0, a[0][i].u.x, 0x128, 0xf, 0xf, true),
+                                               __builtin_amdgcn_update_dpp(0, a[0][i].u.y, 0x128, 0xf, 0xf, true),
+                                               __builtin_amdgcn_update_dpp(0, a[0][i].u.z, 0x128, 0xf, 0xf, true),
+                                               __builtin_amdgcn_update_dpp(0, a[0][i].u.w, 0x128, 0xf, 0xf, true));
+            }
             if (W8) {
                 Frag f0, f1;
                 fp8x16_to_bf16(a[DB ? cur : 0][i].u, f0, f1);
@@ -945,7 +967,9 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     int ssh = 0;
     if (tpw == 1 && gy == 1 && !silu_pairs && pro != 2) {
         // 2 or 4 workgroups per tile while not every CU has one and a workgroup's slice stays above the threshold
-        while (ssh < 2 && (gx << (ssh + 1)) <= 256 && ((a.K * 32) >> (ssh + 1)) >= g_sub_min_bytes) ++ssh;
+        // (bf16 weights: at most two per tile, the kernel's paired requests are built for that; no model shape asks for four)
+        const int ssh_max = a.wscale ? 2 : 1;
+        while (ssh < ssh_max && (gx << (ssh + 1)) <= 256 && ((a.K * 32) >> (ssh + 1)) >= g_sub_min_bytes) ++ssh;
         a.dbg |= ssh << 4;
         gx <<= ssh;
     }
