@@ -85,6 +85,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 __device__ __forceinline__ float row16_xor8(float v) { return dpp_f32<0x128>(v); }   // row_ror:8 == lane ^ 8
 
+__device__ __forceinline__ uint4 dpp_u4_ror8(uint4 v) {      // every dword from lane ^ 8 of the 16-lane row
+    return make_uint4(__builtin_amdgcn_update_dpp(0, v.x, 0x128, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, v.y, 0x128, 0xf, 0xf, true),
+                      __builtin_amdgcn_update_dpp(0, v.z, 0x128, 0xf, 0xf, true), __builtin_amdgcn_update_dpp(0, v.w, 0x128, 0xf, 0xf, true));
+}
+
 union Frag {
     uint4 u;
     u32x4_t n;
@@ -210,10 +215,12 @@ static int g_tune_ksw = 0;   // 0 = automatic
 static int g_tune_t = 0;
 static int g_dbg_linear = 0;
 static int g_rows_min = 32;              // most rows that still take single-tile workgroups instead of the prompt GEMM
+static int g_share_prologue = 1;         // norm prologue shared between the lane halves for up to 8 rows (0: tuning)
 static int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
 extern "C" void qtts_tune_linear(int ksw, int t) { g_tune_ksw = ksw; g_tune_t = t; }
 extern "C" void qtts_tune_subtiles(int min_bytes) { g_sub_min_bytes = min_bytes; }
 extern "C" void qtts_tune_rows(int min_rows) { g_rows_min = min_rows; }
+extern "C" void qtts_tune_shared_prologue(int on) { g_share_prologue = on; }
 extern "C" void qtts_debug_linear(int flags) { g_dbg_linear = flags; }
 static long long *g_trace = nullptr;       // tuning experiments only: timestamp buffer of traced GEMM launches
 static int g_trace_launch = 0;
@@ -278,7 +285,12 @@ struct LinTail {
 };
 #define QTTS_TRACE(slot) do { if (tl.trace && threadIdx.x == 0) tl.trace[(size_t)blockIdx.x * 4 + (slot)] = wall_clock64(); } while (0)
 
-template <int KSW, int PRO, bool DB, int EPI, bool SUB = false, bool W8 = false>
+// H8 (norm prologue, at most 8 rows, one row tile): MFMA columns 8..15 carry no row, so their lanes share the
+// prologue's work instead of repeating it on a copy of row 0: lane (g, r < 8) loads and normalises the EVEN k-steps
+// of row r, lane (g, r + 8) the ODD k-steps of the same row, and a row rotate hands each its partner's result.  Half
+// the activation requests and half the normalisation arithmetic per lane; the sum of squares is added up in the same
+// order in both forms (even k-steps, odd k-steps, then their sum), so both return the same bits.
+template <int KSW, int PRO, bool DB, int EPI, bool SUB = false, bool W8 = false, bool H8 = false>
 __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uint4 *wp, const int64_t *ids, int ldx, int K,
                                                       int N, int M, int tiles_per_wg, int dbg, int id_rows,
                                                       const bf16_t *nw, float eps, const LinTail tl) {
@@ -325,10 +337,14 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
 
     // ---- activation prologue.  Rows beyond M read row 0 instead of being predicated off: their MFMA columns
     // are never stored, and unconditional loads keep the instruction stream ahead of the weight requests short.
+    static_assert(!H8 || (PRO == 1 && KSW % 2 == 0), "shared prologue: norm prologue with an even number of k-steps");
+    const int hi = H8 ? r >> 3 : 0;                         // H8: this lane's k-step parity
+    const int xm = H8 ? (r & 7) : m;                        // the activation row this lane loads
+    const bool xvalid = H8 ? xm < p.M : mvalid;
     Frag xb[KSW];
     size_t xrow = 0;
     {
-        long rid = mvalid ? m : 0;
+        long rid = xvalid ? xm : 0;
         if (p.ids && !(p.dbg & 8)) {
             rid = p.ids[rid];
             rid = rid < 0 ? 0 : (rid >= p.id_rows ? p.id_rows - 1 : rid);
@@ -359,8 +375,10 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
                 ow[j] = pack2(s0 * u0, s1 * u1);
             }
             xb[i].u = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-        } else {
+        } else if (!H8) {
             xb[i].u = *reinterpret_cast<const uint4 *>(xp + 32 * i);
+        } else if (i % 2 == 0) {
+            xb[i].u = *reinterpret_cast<const uint4 *>(xp + 32 * (i + hi));
         }
     }
     // The (small) activation loads above and the norm weights go out first: vector memory requests of a wave are
@@ -369,7 +387,8 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     uint4 nwv[PRO == 1 ? KSW : 1];
     if (PRO == 1) {
 #pragma unroll
-        for (int i = 0; i < KSW; ++i) nwv[i] = *reinterpret_cast<const uint4 *>(p.nw + 32 * (ks0 + i) + 8 * g);
+        for (int i = 0; i < KSW; ++i)
+            if (!H8 || i % 2 == 0) nwv[i] = *reinterpret_cast<const uint4 *>(p.nw + 32 * (ks0 + i + hi) + 8 * g);
     }
     const int kp0 = W8 ? ks0 >> 1 : ks0;
     Frag a[DB ? 2 : 1][NLD];
@@ -415,18 +434,21 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     }
     float *normred = reinterpret_cast<float *>(smem4 + (size_t)2 * NW * 64);
     if (PRO == 1) {
-        float ss = 0.f;
+        // sum of squares: even k-steps, odd k-steps, then their sum (H8: the odd ones are the partner lane's)
+        float sp[2] = {0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < KSW; ++i) {
+            if (H8 && i % 2) continue;
             const uint32_t w4[4] = {xb[i].u.x, xb[i].u.y, xb[i].u.z, xb[i].u.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v0, v1;
                 unpack2(w4[j], v0, v1);
-                ss += v0 * v0;
-                ss += v1 * v1;
+                sp[i & 1] += v0 * v0;
+                sp[i & 1] += v1 * v1;
             }
         }
+        float ss = H8 ? sp[0] + row16_xor8(sp[0]) : sp[0] + sp[1];
         ss += __shfl_xor(ss, 16);
         ss += __shfl_xor(ss, 32);
         if (g == 0) normred[wave * 16 + r] = ss;
@@ -436,7 +458,8 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         const float rstd = 1.0f / sqrtf(tot / (float)p.K + p.eps);
 #pragma unroll
         for (int i = 0; i < KSW; ++i) {
-            const int k = 32 * (ks0 + i) + 8 * g;
+            if (H8 && i % 2) continue;
+            const int k = 32 * (ks0 + i + hi) + 8 * g;
             const uint4 wv = nwv[i];
             const uint32_t x4[4] = {xb[i].u.x, xb[i].u.y, xb[i].u.z, xb[i].u.w}, w4[4] = {wv.x, wv.y, wv.z, wv.w};
             uint32_t o4[4];
@@ -448,8 +471,10 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
                 o4[j] = pack2(rbf(v0 * rstd) * w0, rbf(v1 * rstd) * w1);
             }
             xb[i].u = make_uint4(o4[0], o4[1], o4[2], o4[3]);
-            if (p.xnorm_out && bx == 0 && sub == 0 && mvalid)
-                *reinterpret_cast<uint4 *>(p.xnorm_out + (size_t)m * p.ldxn + k) = xb[i].u;
+            if (p.xnorm_out && bx == 0 && sub == 0 && xvalid)
+                *reinterpret_cast<uint4 *>(p.xnorm_out + (size_t)xm * p.ldxn + k) = xb[i].u;
+            // H8: the partner lane's k-step (lanes r >= 8 end up with a copy of row r - 8: columns never stored)
+            if (H8) xb[i + 1].u = dpp_u4_ror8(xb[i].u);
         }
     }
 
@@ -812,6 +837,7 @@ __global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *par
 
 template <int KSW, int PRO, bool DB, int EPI, bool SUB = false>
 static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs &a) {
+    constexpr bool CAN_H8 = PRO == 1 && KSW % 2 == 0;
     size_t shmem = (size_t)2 * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
     LinTail tl;
     tl.bias = a.bias; tl.res = a.res; tl.ldr = a.ldr; tl.xnorm_out = a.xnorm_out; tl.ldxn = a.ldxn; tl.out = a.out; tl.ldo = a.ldo;
@@ -825,6 +851,13 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
         if (a.wscale) {
             hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI, SUB, true>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids,
                                a.ldx, a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
+            return;
+        }
+    }
+    if constexpr (CAN_H8) {
+        if (a.M <= 8 && !(a.dbg >> 8) && g_share_prologue) {          // one row tile of at most 8 rows
+            hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI, SUB, false, true>), grid, dim3(NW * 64), shmem, s, a.x, a.wp,
+                               a.ids, a.ldx, a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
             return;
         }
     }

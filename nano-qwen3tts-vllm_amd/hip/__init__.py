@@ -79,6 +79,7 @@ _SIGS = {
     "qtts_tune_subtiles": (None, [_i]),
     "qtts_tune_prompt_attention": (None, [_i]),
     "qtts_tune_rows": (None, [_i]),
+    "qtts_tune_shared_prologue": (None, [_i]),
     "qtts_debug_linear": (None, [_i]),
     "qtts_debug_linear_trace": (None, [_p]),
     "qtts_debug_grid_barrier": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
@@ -88,7 +89,7 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-EXPORTED = [n for n in _SIGS if n not in ("qtts_tune_linear", "qtts_tune_subtiles", "qtts_tune_prompt_attention", "qtts_tune_rows", "qtts_debug_linear", "qtts_debug_linear_trace", "qtts_debug_grid_barrier")]
+EXPORTED = [n for n in _SIGS if n not in ("qtts_tune_linear", "qtts_tune_subtiles", "qtts_tune_prompt_attention", "qtts_tune_rows", "qtts_tune_shared_prologue", "qtts_debug_linear", "qtts_debug_linear_trace", "qtts_debug_grid_barrier")]
 
 
 class QttsError(RuntimeError):
