@@ -285,7 +285,7 @@ struct LinTail {
 };
 #define QTTS_TRACE(slot) do { if (tl.trace && threadIdx.x == 0) tl.trace[(size_t)blockIdx.x * 4 + (slot)] = wall_clock64(); } while (0)
 
-// H8 (norm prologue, at most 8 rows, one row tile): MFMA columns 8..15 carry no row, so their lanes share the
+// H8 (at most 8 rows, one row tile; with or without the norm): MFMA columns 8..15 carry no row, so their lanes share the
 // prologue's work instead of repeating it on a copy of row 0: lane (g, r < 8) loads and normalises the EVEN k-steps
 // of row r, lane (g, r + 8) the ODD k-steps of the same row, and a row rotate hands each its partner's result.  Half
 // the activation requests and half the normalisation arithmetic per lane; the sum of squares is added up in the same
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
 
     // ---- activation prologue.  Rows beyond M read row 0 instead of being predicated off: their MFMA columns
     // are never stored, and unconditional loads keep the instruction stream ahead of the weight requests short.
-    static_assert(!H8 || (PRO == 1 && KSW % 2 == 0), "shared prologue: norm prologue with an even number of k-steps");
+    static_assert(!H8 || (PRO != 2 && KSW % 2 == 0), "shared prologue: plain or norm prologue with an even number of k-steps");
     const int hi = H8 ? r >> 3 : 0;                         // H8: this lane's k-step parity
     const int xm = H8 ? (r & 7) : m;                        // the activation row this lane loads
     const bool xvalid = H8 ? xm < p.M : mvalid;
@@ -476,6 +476,12 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             // H8: the partner lane's k-step (lanes r >= 8 end up with a copy of row r - 8: columns never stored)
             if (H8) xb[i + 1].u = dpp_u4_ror8(xb[i].u);
         }
+    }
+
+    if (H8 && PRO == 0) {
+        // no norm: the lane halves still split the activation requests (one request, two k-steps)
+#pragma unroll
+        for (int i = 0; i < KSW; i += 2) xb[i + 1].u = dpp_u4_ror8(xb[i].u);
     }
 
     // ---- tile loop
@@ -837,7 +843,7 @@ __global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *par
 
 template <int KSW, int PRO, bool DB, int EPI, bool SUB = false>
 static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs &a) {
-    constexpr bool CAN_H8 = PRO == 1 && KSW % 2 == 0;
+    constexpr bool CAN_H8 = PRO != 2 && KSW % 2 == 0;
     size_t shmem = (size_t)2 * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
     LinTail tl;
     tl.bias = a.bias; tl.res = a.res; tl.ldr = a.ldr; tl.xnorm_out = a.xnorm_out; tl.ldxn = a.ldxn; tl.out = a.out; tl.ldo = a.ldo;
