@@ -976,6 +976,9 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     int KSW = 0;
     for (int c : ksws)
         if (KS % c == 0 && KS / c <= 8) { KSW = c; break; }
+    // K = 1024: four waves of 8 k-steps beat eight waves of 4 (fewer waves to start, synchronise and reduce; the
+    // predictor's qkv GEMM 4.6 -> 3.8 us, gate/up 5.8 -> 5.3, head 3.3 -> 3.0); K = 2048 measured the same either way
+    if (KSW < 8 && KS % 8 == 0 && KS / 8 >= 4) KSW = 8;
     if (g_tune_ksw > 0 && KS % g_tune_ksw == 0 && KS / g_tune_ksw <= 8)
         for (int c : ksws) if (c == g_tune_ksw) KSW = c;
     QCHECK(KSW > 0, "linear: K=%d not supported (K/32 must factor as <=8 waves x {1,2,4,6,8,12,24})", a.K);
