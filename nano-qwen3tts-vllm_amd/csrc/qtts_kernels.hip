@@ -1968,9 +1968,9 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
         // rows gathered from a table: built for the one-workgroup-per-(row, kv head) variants
         QCHECK(id_rows > 0 && (max_context <= 32 || Hq / Hkv == 4), "attention_decode_fused: gathered rows need max_context <= 32 (got %d)", max_context);
         switch (Hq / Hkv) {
-            case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 16, 2, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+            case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 8, 4, true>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                     else hipLaunchKernelGGL((attn_decode_fused_kernel<1, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
-            case 2: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 16, 2, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+            case 2: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 8, 4, true>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                     else hipLaunchKernelGGL((attn_decode_fused_kernel<2, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
             case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<4, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
             default: QFAIL(QTTS_EINVAL, "attention_decode_fused: unsupported q/kv head ratio %d", Hq / Hkv);
@@ -1979,13 +1979,14 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
         return QTTS_OK;
     }
     switch (Hq / Hkv) {
-        // short contexts (the code predictor's 17 tokens) leave most of a 32-group workgroup idle; two tokens per
-        // 16-lane group cover them (eight would be 16 K/V requests per lane where 4 do)
-        case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 16, 2>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+        // short contexts (the code predictor's 17 tokens) leave most of a 32-group workgroup idle: eight
+        // 16-lane groups (two waves) of four tokens cover 32 tokens (burst 1756 us with sixteen groups of two tokens, 1664 us
+        // with eight of four, 1712 us with four of eight; sixteen groups of eight tokens, 16 K/V requests per lane: 1788 us)
+        case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 8, 4>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                 else if (wide) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32, 8>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                 else hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                 break;
-        case 2: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 16, 2>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+        case 2: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 8, 4>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                 else if (wide) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 32, 8>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                 else hipLaunchKernelGGL((attn_decode_fused_kernel<2, 32>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                 break;
