@@ -1980,7 +1980,7 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
     }
     switch (Hq / Hkv) {
         // short contexts (the code predictor's 17 tokens) leave most of a 32-group workgroup idle: eight
-        // 16-lane groups (two waves) of four tokens cover 32 tokens (burst 1756 us with sixteen groups of two tokens, 1664 us
+        // 16-lane groups (two waves) of four tokens cover 32 tokens (burst 1669 us with sixteen groups of two tokens, 1664 us
         // with eight of four, 1712 us with four of eight; sixteen groups of eight tokens, 16 K/V requests per lane: 1788 us)
         case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 8, 4>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                 else if (wide) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32, 8>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
