@@ -1,6 +1,6 @@
 """Turns the output of tools/refresh_profiles.sh (gpurun_out/refresh/) into the files kept under profiles/.
 
-    python tools/collect_profiles.py [tag]        # tag defaults to v7: r01_bench_line_<tag>.json ...
+    python tools/collect_profiles.py [tag]        # tag defaults to v9: r01_bench_line_<tag>.json ...
 """
 import collections
 import csv
@@ -22,7 +22,7 @@ def last_json(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "v7"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "v9"
     for old in glob.glob(os.path.join(P, "r01_bench_*_v*")):
         os.remove(old)
     bench = last_json(os.path.join(R, "bench_line.json"))
