@@ -546,3 +546,29 @@ def test_prompt_gemm_with_two_row_tiles(hip, M, N, K):
         finally:
             hip.lib.qtts_tune_rows(32)
         assert_bf16_close(got, want, what=f"rows from {min_rows + 1}")
+
+
+@pytest.mark.parametrize("N,K,kind", [(4096, 1024, "norm"), (4096, 2048, "norm"), (2048, 2048, "res"), (1024, 3072, "res"),
+                                      (2048, 6144, "res"), (1024, 2048, "plain"), (6144, 1024, "swiglu"), (12288, 2048, "swiglu")])
+def test_rows_do_not_depend_on_the_row_count_form(hip, N, K, kind):
+    """Up to 8 rows the decode GEMM lets the lanes of the unused MFMA columns share the prologue (half the activation
+    requests and half the normalisation per lane); with 9..16 rows every lane does all of it.  Both forms must return
+    the same bits for a row — the predictor's input tables are built 16 rows per launch and read by 8-row steps."""
+    g = torch.Generator().manual_seed(N + K)
+    x = (torch.randn(16, K, generator=g) * 0.7).bfloat16().to(DEV)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().to(DEV)
+    if kind == "swiglu":
+        I = N // 2
+        wp = hip.pack_gate_up((torch.randn(I, K, generator=g) * 0.05).bfloat16().to(DEV),
+                              (torch.randn(I, K, generator=g) * 0.05).bfloat16().to(DEV))
+        run = lambda rows: hip.linear_swiglu(x[:rows].contiguous(), wp, I, norm_w=nw)
+    else:
+        wp = hip.pack_weight((torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV))
+        res = torch.randn(16, N, generator=g).bfloat16().to(DEV)
+        run = lambda rows: hip.linear(x[:rows].contiguous(), wp, N, norm_w=nw if kind == "norm" else None,
+                                      residual=res[:rows].contiguous() if kind == "res" else None)
+    full = run(16)
+    for rows in (8, 5, 1):
+        part = run(rows)
+        torch.cuda.synchronize()
+        assert torch.equal(part, full[:rows]), f"{kind} {N}x{K}: {rows} rows differ from the 16-row launch"
