@@ -6,9 +6,13 @@
  * own; each entry point below cites the reference function it replaces
  * (P = nano-qwen3tts-vllm/ in the reference tree).  All pointers are DEVICE
  * pointers unless stated otherwise, all tensors are dense row-major, `bf16` is
- * the 16-bit brain float stored as uint16_t.  Every function is asynchronous on
- * `stream` (a hipStream_t passed as void*), allocates nothing, never
- * synchronises, and is therefore legal under hipStreamBeginCapture.
+ * the 16-bit brain float stored as uint16_t.  Every function that takes a
+ * `stream` (a hipStream_t passed as void*) is asynchronous on it, allocates no
+ * device memory, never synchronises, and is therefore legal under
+ * hipStreamBeginCapture.  The set-up calls without a stream argument are not:
+ * qtts_model_create / qtts_graph_end allocate host memory for their handles,
+ * qtts_model_set_workspace clears the workspace's counters with a synchronous
+ * hipMemset; call them outside capture.
  *
  * Return value: 0 on success, a negative QTTS_E* code on a rejected argument
  * (nothing was launched), or a positive hipError_t from the launch.
@@ -215,11 +219,16 @@ int qtts_frame_glue(const void *talker_emb, const void *const *pred_emb_tables /
 /* Device-side equivalent of re-running prepare_decode_talker for the next token
  * (P/engine/model_runner/talker_mode_runner.py:116-140) for every active row
  * (context_lens > 0): position+1, context+1, slot from the row's block table,
- * frame_idx+1; *rng_counter += 64 (nullable).  No counterpart in the reference (it
- * rebuilds the lists on the host). */
+ * frame_idx+1; *rng_counter += 64 (nullable).  A row whose context has reached
+ * min(max_context, context_limits[b]) (context_limits nullable: max_context alone) is
+ * frozen — the host sets the limit to the tokens the row's KV blocks were reserved for,
+ * so a row stepped past its budget rewrites its own last slot and never walks into a
+ * block-table entry that is not its own.  No counterpart in the reference (it rebuilds
+ * the lists on the host and has no length guard, P/engine/llm_engine/talker_llm_engine.py:68-83). */
 int qtts_advance_decode(int64_t *positions, int32_t *slot_mapping, int32_t *context_lens,
                         const int32_t *block_tables, int max_blocks, int32_t *frame_idx,
-                        uint64_t *rng_counter, int max_context, int B, qtts_stream_t stream);
+                        uint64_t *rng_counter, const int32_t *context_limits, int max_context, int B,
+                        qtts_stream_t stream);
 
 /* ---------------------------------------------------------------- decoder stack
  * One handle per model (talker or code predictor): the layer loop of
@@ -248,6 +257,9 @@ int qtts_model_set_final_norm(qtts_model_t *m, const void *w);
 int qtts_model_set_rope(qtts_model_t *m, const void *cos, const void *sin, int max_pos);
 /* kv: [2, n_layers, num_blocks, 256, n_kv_heads, 128] bf16 (P/engine/model_runner/base.py:158-164). */
 int qtts_model_set_kv_cache(qtts_model_t *m, void *kv, int num_blocks);
+/* Device scratch of a model: activations for max_rows rows (the largest packed prompt batch,
+ * max_num_batched_tokens) and the attention partials of the rows that can need them (a decode step takes at most 512
+ * rows, the reference's max_num_seqs, P/config.py:45).  set_workspace clears the counters in it (synchronous). */
 size_t qtts_model_workspace_bytes(const qtts_model_t *m, int max_rows, int max_context);
 int qtts_model_set_workspace(qtts_model_t *m, void *ws, size_t bytes, int max_rows, int max_context);
 
@@ -293,40 +305,6 @@ int qtts_model_forward_logits_pairs(qtts_model_t *m, const void *x, const int64_
                                     const int32_t *slot_mapping, int N, void *hidden_out,
                                     const void *head_w_packed, int vocab, void *logits_out,
                                     qtts_stream_t stream);
-
-/* ---------------------------------------------------------------- resident burst
- * The code predictor's whole burst for up to 8 sequences — the 2-position prefill and
- * n_gen-1 decode steps with head, pick and token feedback
- * (P/engine/model_runner/predictor_model_runner.py:134-157 driven 15 times by
- * P/workers/predictor_worker.py:128-134) — as ONE kernel that stays on the chip and walks
- * a table of stages with a device-wide barrier between them, instead of one launch per
- * stage.  Same arithmetic and rounding points as the per-stage entry points above.  (On
- * MI355X the graph of per-stage launches measured faster; the host keeps this opt-in.)
- *   qtts_burst_program_bytes : device bytes for the stage table + barrier words
- *   qtts_burst_build         : fills the table (synchronous upload; call outside graph
- *                              capture, once per batch size / buffer set).  `inputs` are the
- *                              2*bs prompt rows [talker_hidden] (pairs per sequence); rows of
- *                              positions / slot_mapping / context_lens are laid out as 2*bs
- *                              prefill rows followed by n_gen-1 groups of bs decode rows;
- *                              emb_tables / heads_packed are HOST arrays of n_gen device
- *                              pointers; tokens_out[step*bs + i] receives the ids.
- *   qtts_burst_launch        : clears the barrier words and launches n_workgroups (<= CU
- *                              count: they must all be on the chip at once) x 512 threads.
- *                              barrier_group >= n_workgroups: one flat arrival counter.
- *   qtts_burst_status        : 0 after a burst that ran to its end, 1 if a workgroup gave up
- *                              waiting at a barrier (synchronous read).
- * Limits: bs <= 8, q/kv head ratio 1 or 2, K of every GEMM <= 3072 and hidden <= 2048. */
-size_t qtts_burst_program_bytes(const qtts_model_t *m, int n_gen, int has_projection);
-int qtts_burst_build(qtts_model_t *m, void *program, size_t program_bytes, int bs, const void *inputs,
-                     int talker_hidden, const void *proj_w_packed, const void *proj_bias, void *x_buf,
-                     const void *const *emb_tables, int emb_rows, const void *const *heads_packed, int n_gen,
-                     int vocab, const int64_t *positions, const int32_t *slot_mapping,
-                     const int32_t *context_lens, const int32_t *block_tables, int max_blocks, void *logits,
-                     int64_t *tokens_out);
-int qtts_burst_launch(qtts_model_t *m, void *program, int n_gen, int has_projection, int n_workgroups,
-                      int barrier_group, const float *temperatures, const uint8_t *greedy_flags, int top_k,
-                      uint64_t seed, const uint64_t *rng_offset, int max_blocks, qtts_stream_t stream);
-int qtts_burst_status(const qtts_model_t *m, const void *program, int n_gen, int has_projection);
 
 /* ---------------------------------------------------------------- hipGraph helpers
  * Capture a sequence of the calls above once per batch size and replay it

@@ -211,20 +211,32 @@ extern "C" int qtts_pack_gate_up_fp8(const void *gate, const void *up, void *pac
     return QTTS_OK;
 }
 
+// Dispatch thresholds.  The shipped library holds them as constants; a -DQTTS_TUNING build (tools/ only, see
+// csrc/build.py --tuning) turns them into process-wide variables with setters for A/B measurements.
+#ifdef QTTS_TUNING
 static int g_tune_ksw = 0;   // 0 = automatic
 static int g_tune_t = 0;
 static int g_dbg_linear = 0;
 static int g_rows_min = 32;              // most rows that still take single-tile workgroups instead of the prompt GEMM
 static int g_share_prologue = 1;         // norm prologue shared between the lane halves for up to 8 rows (0: tuning)
 static int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
+static int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention takes the MFMA kernel for prompts
 extern "C" void qtts_tune_linear(int ksw, int t) { g_tune_ksw = ksw; g_tune_t = t; }
 extern "C" void qtts_tune_subtiles(int min_bytes) { g_sub_min_bytes = min_bytes; }
 extern "C" void qtts_tune_rows(int min_rows) { g_rows_min = min_rows; }
 extern "C" void qtts_tune_shared_prologue(int on) { g_share_prologue = on; }
+extern "C" void qtts_tune_prompt_attention(int min_rows) { g_mfma_attn_rows = min_rows; }
 extern "C" void qtts_debug_linear(int flags) { g_dbg_linear = flags; }
-static long long *g_trace = nullptr;       // tuning experiments only: timestamp buffer of traced GEMM launches
+static long long *g_trace = nullptr;       // timestamp buffer of traced GEMM launches
 static int g_trace_launch = 0;
 extern "C" void qtts_debug_linear_trace(long long *buf) { g_trace = buf; g_trace_launch = 0; }
+#else
+static constexpr int g_tune_ksw = 0, g_tune_t = 0, g_dbg_linear = 0;
+static constexpr int g_rows_min = 32;              // most rows that still take single-tile workgroups instead of the prompt GEMM
+static constexpr int g_share_prologue = 1;         // norm prologue shared between the lane halves for up to 8 rows
+static constexpr int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
+static constexpr int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention takes the MFMA kernel for prompts
+#endif
 
 // ------------------------------------------------------------------ linear (skinny GEMM on MFMA)
 // One kernel shape for every projection.  Workgroup = NW <= 8 waves, wave w owns
@@ -280,10 +292,16 @@ struct LinTail {
     const bf16_t *bias, *res; int ldr;
     bf16_t *xnorm_out; int ldxn;
     bf16_t *out; int ldo;
-    long long *trace;     // tuning experiments only (null in production): 4 timestamps per workgroup
     const float *wscale;  // fp8 weights: one power-of-two scale per packed weight row
+#ifdef QTTS_TUNING
+    long long *trace;     // 4 timestamps per workgroup
+#endif
 };
+#ifdef QTTS_TUNING
 #define QTTS_TRACE(slot) do { if (tl.trace && threadIdx.x == 0) tl.trace[(size_t)blockIdx.x * 4 + (slot)] = wall_clock64(); } while (0)
+#else
+#define QTTS_TRACE(slot) do { } while (0)
+#endif
 
 // H8 (at most 8 rows, one row tile; with or without the norm): MFMA columns 8..15 carry no row, so their lanes share the
 // prologue's work instead of repeating it on a copy of row 0: lane (g, r < 8) loads and normalises the EVEN k-steps
@@ -607,13 +625,19 @@ struct RowsArgs {
     float *part; int mpad;       // EPI 2: part[kpart][mpad][N]
     int rgroups, KS;             // row groups of TM tiles; k-steps of a whole packed weight tile
     const float *wscale;         // fp8 weights: scale per packed weight row
-    long long *trace;            // tuning experiments only (null in production): 32 timestamps per workgroup
+#ifdef QTTS_TUNING
+    long long *trace;            // 32 timestamps per workgroup
+#endif
 };
 
 template <int KSW, int TM, int EPI, bool W8 = false>
 __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const uint4 *wp, int ldx, int N, int M,
                                                           int tiles_per_wg, const RowsArgs p) {
+#ifdef QTTS_TUNING
 #define QTTS_RTRACE(slot) do { if (p.trace && threadIdx.x == 0 && (slot) < 32) p.trace[(size_t)blockIdx.x * 32 + (slot)] = wall_clock64(); } while (0)
+#else
+#define QTTS_RTRACE(slot) do { } while (0)
+#endif
     QTTS_RTRACE(0);
     extern __shared__ float4_t smem4[];
     const int lane = threadIdx.x & 63;
@@ -847,11 +871,13 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
     size_t shmem = (size_t)2 * NW * 64 * sizeof(float4_t) + (size_t)NW * 16 * sizeof(float);
     LinTail tl;
     tl.bias = a.bias; tl.res = a.res; tl.ldr = a.ldr; tl.xnorm_out = a.xnorm_out; tl.ldxn = a.ldxn; tl.out = a.out; tl.ldo = a.ldo;
+#ifdef QTTS_TUNING
     tl.trace = nullptr;
     if (g_trace) {
         tl.trace = g_trace + (size_t)g_trace_launch * 4 * 1024;      // up to 1024 workgroups per traced launch
         ++g_trace_launch;
     }
+#endif
     tl.wscale = a.wscale;
     if constexpr (KSW % 2 == 0 && PRO != 2) {
         if (a.wscale) {
@@ -917,7 +943,9 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     RowsArgs r;
     r.bias = a.bias; r.res = a.res; r.ldr = a.ldr; r.out = a.out; r.ldo = a.ldo;
     r.part = scratch; r.mpad = a.M; r.rgroups = (mtiles + TM - 1) / TM; r.KS = KS;
+#ifdef QTTS_TUNING
     r.trace = g_trace;
+#endif
     r.wscale = a.wscale;
     const int ntiles = a.N / 16;
     // One round of workgroups (a CU holds one, an XCD 32): workgroup i runs on XCD i % 8 and the launch is laid out
@@ -1577,9 +1605,6 @@ __global__ __launch_bounds__(512) void prefill_attn_mfma_kernel(
     }
 }
 
-static int g_mfma_attn_rows = 112;      // rows from which qtts_paged_attention takes the MFMA kernel for prompts
-extern "C" void qtts_tune_prompt_attention(int min_rows) { g_mfma_attn_rows = min_rows; }
-
 static inline int attn_nsplit(int max_context) { return max_context <= ATT_SPLIT ? 1 : (max_context + ATT_SPLIT - 1) / ATT_SPLIT; }
 
 extern "C" size_t qtts_attn_workspace_bytes(int N, int Hq, int max_context) {
@@ -1733,7 +1758,9 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
     // the row's metadata: four independent requests in one batch, no branch between them (a null slot array reads
     // the context length in its place and is sorted out afterwards)
     const int blk_all = a_tables[(size_t)row * a_max_blocks + (t0 >> 8)];
-    const int ctx = a_ctx[row];
+    // a context beyond what this launch's grid covers (the host's max_context) is cut to it: every split the
+    // row counts on exists, so the arrival counter always completes and `out` is always written
+    const int ctx = min(a_ctx[row], a_nsplit * SPLIT);
     const int slot_raw = (a_slots ? a_slots : a_ctx)[row];
     long pos = a_pos[row];
     long qrow = IDS ? p.row_ids[row] : row;
@@ -1902,7 +1929,14 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
     // The last of the row's workgroups to arrive merges the partials.  Partials and counter are accessed
     // with device-scope atomics only (they go to the level all XCDs share), the barrier waits for this
     // workgroup's stores to be acknowledged before the counter moves, so no whole-cache write-back or
-    // invalidate is needed.
+    // invalidate is needed.  This is an argument about gfx950, not about the HIP memory model (which would ask
+    // for a release on the counter and an acquire on the merging side, i.e. exactly that write-back / invalidate,
+    // measured at about 19 us per launch): agent-scope atomic stores and loads bypass the per-XCD L2 (sc1), stores
+    // are counted by vmcnt until acknowledged, and the counter add below is issued after the wait and the barrier.
+    // Another target needs this looked at again, hence the guard.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "attn_decode_fused_kernel: the relaxed partial/counter protocol is argued for gfx950 only"
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2482,16 +2516,19 @@ extern "C" int qtts_frame_glue(const void *talker_emb, const void *const *pred_e
 // Advances the per-stream decode metadata by one token on the device, so that a captured
 // frame graph can be replayed without a host upload: for active rows (context_lens > 0)
 // position += 1, context += 1, slot = table[(context-1) / 256] * 256 + (context-1) % 256,
-// frame_idx += 1.  Rows that would exceed max_context are frozen (context stays put).
+// frame_idx += 1.  A row whose context has reached max_context, or its own limit context_limits[b] (the tokens its
+// KV blocks were reserved for), is frozen: nothing moves, so the row keeps rewriting its own last slot and can
+// never reach a block-table entry that is not its own.
 __global__ void advance_decode_kernel(int64_t *__restrict__ positions, int32_t *__restrict__ slots,
                                       int32_t *__restrict__ ctx, const int32_t *__restrict__ tables, int max_blocks,
                                       int32_t *__restrict__ frame_idx, uint64_t *__restrict__ rng_counter,
-                                      int max_context, int B) {
+                                      const int32_t *__restrict__ limits, int max_context, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0 && rng_counter) *rng_counter += 64;      // 64 distinct RNG offsets per frame
     if (b >= B) return;
     const int c = ctx[b];
-    if (c <= 0 || c >= max_context) return;
+    const int lim = limits ? min(limits[b], max_context) : max_context;
+    if (c <= 0 || c >= lim) return;
     const int n = c + 1;
     ctx[b] = n;
     positions[b] += 1;
@@ -2501,11 +2538,13 @@ __global__ void advance_decode_kernel(int64_t *__restrict__ positions, int32_t *
 
 extern "C" int qtts_advance_decode(int64_t *positions, int32_t *slot_mapping, int32_t *context_lens,
                                    const int32_t *block_tables, int max_blocks, int32_t *frame_idx,
-                                   uint64_t *rng_counter, int max_context, int B, qtts_stream_t stream) {
+                                   uint64_t *rng_counter, const int32_t *context_limits, int max_context, int B,
+                                   qtts_stream_t stream) {
     QCHECK(positions && slot_mapping && context_lens && block_tables && B > 0 && max_blocks > 0 &&
                max_context <= max_blocks * QTTS_KV_BLOCK, "advance_decode: bad arguments");
     hipLaunchKernelGGL(advance_decode_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, positions,
-                       slot_mapping, context_lens, block_tables, max_blocks, frame_idx, rng_counter, max_context, B);
+                       slot_mapping, context_lens, block_tables, max_blocks, frame_idx, rng_counter, context_limits,
+                       max_context, B);
     QLAUNCH();
     return QTTS_OK;
 }
@@ -2633,6 +2672,7 @@ extern "C" int qtts_model_set_kv_cache(qtts_model_t *m, void *kv, int num_blocks
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+#define QTTS_MAX_DECODE_ROWS 512   // sequences per decode step: the reference's max_num_seqs (P/config.py:45)
 
 struct WsLayout {
     size_t qkv, attn, act, xa, xb, xn, parts, parts_bytes, att_ws, att_cnt, total;
@@ -2650,11 +2690,21 @@ static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
     L.xn = off; off += align256((size_t)rows * m->hidden * 2);       // normalised rows of a prompt (prefill GEMMs)
     L.parts_bytes = linear_rows_scratch_bytes(rows, m->hidden, m->inter);   // K parts of a prompt's down projection
     L.parts = off; off += align256(L.parts_bytes);
-    // prefill and decode attention share the partials region; the decode kernel's arrival counters follow it
-    const size_t pre = qtts_attn_workspace_bytes(rows, m->n_heads, max_context);
-    const size_t dec = attn2_partial_bytes(rows, m->n_heads, max_context);
+    // prefill and decode attention share the partials region; the decode kernel's arrival counters follow it.
+    // Partials exist per (row, head, 128-token split), 520 bytes each: sized for the rows that can need them, not
+    // for every row of the largest prompt batch.  Decode: at most QTTS_MAX_DECODE_ROWS sequences per step.
+    // Prompts: with 1 or 2 query heads per KV head only launches below the MFMA kernel's row threshold use the
+    // per-row kernel (and its partials).
+    const int dec_rows = std::min(rows, QTTS_MAX_DECODE_ROWS);
+#ifdef QTTS_TUNING
+    const int pre_rows = rows;                          // the row threshold is a run-time variable in this build
+#else
+    const int pre_rows = m->n_heads / m->n_kv_heads <= 2 ? std::min(rows, g_mfma_attn_rows) : rows;
+#endif
+    const size_t pre = qtts_attn_workspace_bytes(pre_rows, m->n_heads, max_context);
+    const size_t dec = attn2_partial_bytes(dec_rows, m->n_heads, max_context);
     L.att_ws = off; off += align256(pre > dec ? pre : dec);
-    L.att_cnt = off; off += align256((size_t)rows * m->n_kv_heads * sizeof(int));
+    L.att_cnt = off; off += align256((size_t)dec_rows * m->n_kv_heads * sizeof(int));
     L.total = off;
     return L;
 }
@@ -2698,6 +2748,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     // pairs: rows (2i, 2i+1) are the two positions of a fresh sequence i; the head (required) runs on the second rows
     QCHECK(!pairs || (N % 2 == 0 && N <= 16 && !row_seq && !x_ids && head_w), "model_forward: bad 2-position prompt arguments");
     QCHECK(N > 0 && N <= m->ws_rows, "model_forward: N=%d exceeds workspace rows %d", N, m->ws_rows);
+    QCHECK(row_seq || N <= QTTS_MAX_DECODE_ROWS, "model_forward: a decode step takes at most %d rows (got %d)", QTTS_MAX_DECODE_ROWS, N);
     QCHECK(max_context > 0 && max_context <= m->ws_ctx, "model_forward: max_context=%d exceeds workspace %d", max_context, m->ws_ctx);
     QCHECK(pairs || (max_blocks > 0 && max_context <= max_blocks * QTTS_KV_BLOCK), "model_forward: max_context exceeds block table");
     const WsLayout W = ws_layout(m, m->ws_rows, m->ws_ctx);
@@ -2826,6 +2877,8 @@ extern "C" int qtts_model_forward_logits_pairs(qtts_model_t *m, const void *x, c
                               vocab, logits_out, stream, nullptr, 0, nullptr, true);
 }
 
+#ifdef QTTS_TUNING
+#include "qtts_tuning.h"
 // ------------------------------------------------------------------ grid barrier probe (tuning experiments only)
 // `iters` device-wide barriers inside one resident kernel.  mode 0: every workgroup adds to one counter and polls
 // it.  mode 1: one arrival counter, the last arriver publishes the round number to per-group flags (256 B apart)
@@ -2894,6 +2947,7 @@ extern "C" int qtts_debug_grid_barrier(int *mem, int iters, int nwg, int threads
 }
 
 #include "qtts_resident.inc"
+#endif  // QTTS_TUNING
 
 // ------------------------------------------------------------------ hipGraph helpers
 struct qtts_graph {

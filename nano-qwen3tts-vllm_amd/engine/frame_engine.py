@@ -18,8 +18,6 @@ work for embedding-fed sequences.
 """
 from __future__ import annotations
 
-import ctypes
-
 import torch
 
 from .. import hip
@@ -35,8 +33,8 @@ class NoCapacity(RuntimeError):
 
 
 class Stream:
-    def __init__(self, sid, row, seq, n_text):
-        self.sid, self.row, self.seq, self.n_text = sid, row, seq, n_text
+    def __init__(self, sid, row, seq, n_text, max_frames):
+        self.sid, self.row, self.seq, self.n_text, self.max_frames = sid, row, seq, n_text, max_frames
         self.frames: list[list[int]] = []
         self.finished = False
 
@@ -69,6 +67,8 @@ class FrameEngine:
         self.codes = torch.zeros(max_streams, 16, dtype=torch.int64, device=dev)
         self.text_add = torch.zeros(max_streams, max_text_frames, H, dtype=torch.float32, device=dev)
         self.frame_idx = torch.zeros(max_streams, dtype=torch.int32, device=dev)
+        # per row: the context length its reserved KV blocks cover; the device-side metadata advance stops there
+        self.ctx_limit = torch.zeros(max_streams, dtype=torch.int32, device=dev)
         self.rng = torch.zeros(1, dtype=torch.int64, device=dev)
         self.temps_t = torch.ones(max_streams, dtype=torch.float32, device=dev)
         self.temps_p = torch.ones(max_streams, dtype=torch.float32, device=dev)
@@ -88,7 +88,6 @@ class FrameEngine:
         # nothing is stored, nothing advances) so that no code object is first loaded under capture.
         with self.tr.on_stream():
             self._setup_predictor_meta(1)
-            self.pr.prepare_resident(1)
             self._frame_body(1, 128)
             self._frame_body(1, 256)
             self.rng.zero_()
@@ -126,6 +125,7 @@ class FrameEngine:
             self.cur_hidden[row].copy_(hidden[0])
             self.cur_token[row] = toks[0]
             self.frame_idx[row] = 0
+            self.ctx_limit[row] = total - 1                # the talker step that closes frame max_frames - 1
             self.temps_t[row] = tsp.temperature
             self.temps_p[row] = psp.temperature
             self.greedy[row] = 0 if (tsp.do_sample or psp.do_sample) else 1
@@ -139,7 +139,7 @@ class FrameEngine:
             tab[row].fill_(0)
             tab[row, :need] = torch.tensor(seq.block_table, dtype=torch.int32)
             self._sync_row_to_device(row)
-        s = Stream(sid, row, seq, F)
+        s = Stream(sid, row, seq, F, max_frames)
         s.first_token = toks[0]
         self.rows[row] = s
         self.streams[sid] = s
@@ -220,7 +220,7 @@ class FrameEngine:
         st, mb = tr.dstage, tr.max_blocks_per_seq
         hip.check(lib.qtts_advance_decode(hip.ptr(st.d("positions")), hip.ptr(st.d("slots")), hip.ptr(st.d("ctx")),
                                           hip.ptr(st.d("tables")), mb, hip.ptr(self.frame_idx), hip.ptr(self.rng),
-                                          tr.config.max_model_len, bs, s()), "advance_decode")
+                                          hip.ptr(self.ctx_limit), tr.config.max_model_len, bs, s()), "advance_decode")
         tr.decoder.forward_logits(self.next_x[:bs], st.d("positions")[:bs], st.d("slots")[:bs], st.d("ctx")[:bs],
                                   st.d("tables")[:bs * mb].view(bs, mb), max_context, tr.codec_head, tr.vocab,
                                   hidden_out=self.cur_hidden[:bs], logits_out=tr.logits[:bs])
@@ -235,12 +235,10 @@ class FrameEngine:
 
     def _launch_codes(self, bs):
         if self.enforce_eager:
-            self.pr.prepare_resident(bs)
             self._codes_part(bs)
             return
         g = self.code_graphs.get(bs)
         if g is None:
-            self.pr.prepare_resident(bs)          # uploads a stage table: not allowed while capturing
             g = self.code_graphs[bs] = hip.Graph.capture(lambda: self._codes_part(bs))
         g.launch()
 
@@ -264,7 +262,6 @@ class FrameEngine:
         top = min(max_context or self.tr.config.max_model_len, self.tr.config.max_model_len)
         with self.tr.on_stream():
             for bs in (b for b in self.tr.graph_bs if b <= self._bucket_for(self.max_streams)):
-                self.pr.prepare_resident(bs)
                 self._setup_predictor_meta(bs)
                 if bs not in self.code_graphs:
                     self.code_graphs[bs] = hip.Graph.capture(lambda: self._codes_part(bs))
@@ -279,7 +276,12 @@ class FrameEngine:
 
     def run_frames(self, n: int) -> torch.Tensor:
         """Generate n frames for every active stream back to back (no EOS handling: the caller asked
-        for exactly n).  Returns ids [n, bucket, 16] on the host; one synchronisation at the end."""
+        for exactly n; a stream with fewer than n frames left of its max_frames is an error, its KV blocks were
+        reserved for max_frames).  Returns ids [n, bucket, 16] on the host; one synchronisation at the end."""
+        for s in self.streams.values():
+            if len(s.frames) + n > s.max_frames:
+                raise ValueError(f"stream {s.sid}: {n} more frames exceed its max_frames={s.max_frames} "
+                                 f"({len(s.frames)} generated)")
         bs = self._bucket()
         out = torch.empty(n, bs, 16, dtype=torch.int64).pin_memory()
         with self.tr.on_stream():
@@ -296,7 +298,8 @@ class FrameEngine:
 
     def step(self) -> dict[str, list[int]]:
         """One frame for every active stream; streams whose talker id is the codec EOS finish
-        without yielding that frame (as P/interface.py:1233-1239)."""
+        without yielding that frame (as P/interface.py:1233-1239); a stream that has produced its max_frames
+        finishes with that frame (the explicit length guard the reference lacks)."""
         if not self.streams:
             return {}
         bs = self._bucket()
@@ -320,6 +323,9 @@ class FrameEngine:
                 continue
             s.frames.append(c)
             res[s.sid] = c
+            if len(s.frames) >= s.max_frames:
+                s.finished = True
+                self.remove_stream(s.sid)
         return res
 
     def exit(self):

@@ -11,7 +11,6 @@ Two ways to run a request:
 """
 from __future__ import annotations
 
-import ctypes
 import os
 from typing import Optional
 
@@ -93,12 +92,9 @@ class PredictorModelRunner(ModelRunner):
                                ("tables", self.max_bs * mb, torch.int32), ("rng", 1, torch.int64),
                                ("temps", self.max_bs, torch.float32), ("greedy", self.max_bs, torch.int32)], self.device)
         self.burst_tokens = torch.zeros(self.n_gen * self.max_bs, dtype=torch.int64, device=self.device)
-        # resident burst (one kernel per burst, stages separated by device-wide barriers): programs per batch size.
-        # Opt-in: on MI355X it measured slower than the graph of per-stage launches (3.2 ms against 2.3 ms).
-        self.resident = os.environ.get("QTTS_PREDICTOR_RESIDENT", "0") == "1"
-        self.resident_wgs = int(os.environ.get("QTTS_RESIDENT_WGS", "256"))
-        self.resident_group = int(os.environ.get("QTTS_RESIDENT_GROUP", "16"))
-        self._programs: dict[int, torch.Tensor] = {}
+        # every step of a burst leaves its logits in a slice of its own (rows 0..bs-1 of burst_logits[step]): the
+        # distribution behind each of the 15 picks of a frame stays readable after the burst
+        self.burst_logits = torch.zeros(self.n_gen, self.max_bs, self.vocab, dtype=torch.bfloat16, device=self.device)
 
     # ---- pieces ---------------------------------------------------------------------
     def _fold_tables(self):
@@ -217,50 +213,13 @@ class PredictorModelRunner(ModelRunner):
         return self._pick(seqs, S)
 
     # ---- the fused burst ----------------------------------------------------------------
-    def resident_ok(self, bs: int) -> bool:
-        s = self.shape
-        return (self.resident and bs <= 8 and s.num_heads // s.num_kv_heads in (1, 2) and s.hidden_size <= 2048
-                and s.intermediate_size <= 3072 and self.talker_hidden <= 3072 and self.vocab <= 4096
-                and (self.proj_w is not None or s.intermediate_size >= s.hidden_size))
-
-    def prepare_resident(self, bs: int):
-        """Builds the stage table of the resident burst kernel for this batch size (synchronous upload: must
-        happen outside graph capture)."""
-        if bs in self._programs or not self.resident_ok(bs):
-            return
-        lib, st, proj = hip.lib, self.bstage, self.proj_w is not None
-        h = self.decoder._h
-        nbytes = lib.qtts_burst_program_bytes(h, self.n_gen, int(proj))
-        prog = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
-        arr = ctypes.c_void_p * self.n_gen
-        tabs = arr(*[t.data_ptr() for t in self.tables])
-        heads = arr(*[t.data_ptr() for t in self.heads])
-        hip.check(lib.qtts_burst_build(h, hip.ptr(prog), nbytes, bs, hip.ptr(self.e_buf), self.talker_hidden,
-                                       hip.ptr(self.proj_w) if proj else None, hip.ptr(self.proj_b) if proj else None,
-                                       hip.ptr(self.x_buf), tabs, self.tables[0].shape[0], heads, self.n_gen, self.vocab,
-                                       hip.ptr(st.d("positions")), hip.ptr(st.d("slots")), hip.ptr(st.d("ctx")),
-                                       hip.ptr(st.d("tables")), self.max_blocks_per_seq, hip.ptr(self.logits),
-                                       hip.ptr(self.burst_tokens)), "burst_build")
-        self._programs[bs] = prog
-
-    def resident_status(self, bs: int) -> int:
-        return hip.lib.qtts_burst_status(self.decoder._h, hip.ptr(self._programs[bs]), self.n_gen,
-                                         int(self.proj_w is not None))
-
     def _burst_body(self, bs: int):
-        if bs in self._programs:
-            hip.check(hip.lib.qtts_burst_launch(self.decoder._h, hip.ptr(self._programs[bs]), self.n_gen,
-                                                int(self.proj_w is not None), self.resident_wgs, self.resident_group,
-                                                hip.ptr(self._burst_temps), hip.ptr(self._greedy_bytes), self._top_k,
-                                                self.rng_seed, hip.ptr(self._burst_rng), self.max_blocks_per_seq,
-                                                hip.stream()), "burst_launch")
-            return
         st, mb, h, Ht = self.bstage, self.max_blocks_per_seq, self.shape.hidden_size, self.talker_hidden
         tables = st.d("tables")[:bs * mb].view(bs, mb)
         stream = hip.stream
 
         def pick(step):
-            hip.check(hip.lib.qtts_pick_token(hip.ptr(self.logits), self.vocab, hip.ptr(self._burst_temps),
+            hip.check(hip.lib.qtts_pick_token(hip.ptr(self.burst_logits[step]), self.vocab, hip.ptr(self._burst_temps),
                                               hip.ptr(self._greedy_bytes), self._top_k, self.rng_seed, step,
                                               hip.ptr(self._burst_rng), hip.ptr(self.burst_tokens) + 8 * step * bs, 1,
                                               bs, self.vocab, stream()), "pick_token")
@@ -272,14 +231,14 @@ class PredictorModelRunner(ModelRunner):
             # one attention launch per layer for both positions, final norm inside the head GEMM (second rows only)
             hip.check(hip.lib.qtts_model_forward_logits_pairs(self.decoder._h, hip.ptr(x), hip.ptr(st.d("positions")),
                                                               hip.ptr(st.d("slots")), n0, hip.ptr(self.h_buf),
-                                                              hip.ptr(self.heads[0]), self.vocab, hip.ptr(self.logits),
+                                                              hip.ptr(self.heads[0]), self.vocab, hip.ptr(self.burst_logits[0]),
                                                               stream()), "model_forward_logits_pairs")
         else:
             self.decoder.forward(x, st.d("positions")[:n0], st.d("slots")[:n0], st.d("ctx")[:n0], tables, 2,
                                  row_seq=st.d("row_seq")[:n0], out=self.h_buf[:n0])
             # last position of each sequence = odd rows: a strided view, no gather needed
             hip.check(hip.lib.qtts_linear(hip.ptr(self.h_buf) + 2 * h, 2 * h, hip.ptr(self.heads[0]), None, None, 0, None,
-                                          0.0, hip.ptr(self.logits), self.vocab, bs, self.vocab, h, stream()), "head0")
+                                          0.0, hip.ptr(self.burst_logits[0]), self.vocab, bs, self.vocab, h, stream()), "head0")
         pick(0)
         off = n0
         for step in range(1, self.n_gen):
@@ -290,7 +249,7 @@ class PredictorModelRunner(ModelRunner):
                 hip.check(hip.lib.qtts_model_forward_logits_gathered(
                     self.decoder._h, hip.ptr(xt), hip.ptr(qt), prev, xt.shape[0], hip.ptr(st.d("positions")[off:off + bs]),
                     hip.ptr(st.d("slots")[off:off + bs]), hip.ptr(st.d("ctx")[off:off + bs]), hip.ptr(tables), mb, step + 2,
-                    bs, hip.ptr(self.h_buf), hip.ptr(self.heads[step]), self.vocab, hip.ptr(self.logits), stream()),
+                    bs, hip.ptr(self.h_buf), hip.ptr(self.heads[step]), self.vocab, hip.ptr(self.burst_logits[step]), stream()),
                     "model_forward_logits_gathered")
                 pick(step)
                 off += bs
@@ -307,7 +266,7 @@ class PredictorModelRunner(ModelRunner):
                 x = self.e_buf[:bs]
             self.decoder.forward_logits(x, st.d("positions")[off:off + bs], st.d("slots")[off:off + bs],
                                         st.d("ctx")[off:off + bs], tables, step + 2, self.heads[step], self.vocab,
-                                        hidden_out=self.h_buf[:bs], logits_out=self.logits[:bs])
+                                        hidden_out=self.h_buf[:bs], logits_out=self.burst_logits[step, :bs])
             pick(step)
             off += bs
 
@@ -352,7 +311,6 @@ class PredictorModelRunner(ModelRunner):
         self._burst_temps, self._burst_rng = st.d("temps"), st.d("rng")
         rows = [s.input_embeds.reshape(-1, s.input_embeds.shape[-1]) for s in seqs]
         self.e_buf[:2 * S].copy_(torch.cat(rows, 0).to(torch.bfloat16), non_blocking=True)
-        self.prepare_resident(bs)
         if self.enforce_eager:
             self._burst_body(bs)
         else:

@@ -56,7 +56,7 @@ _SIGS = {
     "qtts_embedding_gather": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "qtts_predictor_input": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "qtts_frame_glue": (_i, [_p, _p, _p, _p, _i, _p, C.c_long, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "qtts_advance_decode": (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _i, _p]),
+    "qtts_advance_decode": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
     "qtts_model_create": (_p, [_i, _i, _i, _i, _i, _i, _f]),
     "qtts_model_destroy": (None, [_p]),
     "qtts_model_set_layer_fp8": (_i, [_p, _i] + [_p] * 12),
@@ -67,29 +67,17 @@ _SIGS = {
     "qtts_model_workspace_bytes": (_sz, [_p, _i, _i]),
     "qtts_model_set_workspace": (_i, [_p, _p, _sz, _i, _i]),
     "qtts_model_forward": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p]),
-    "qtts_burst_program_bytes": (_sz, [_p, _i, _i]),
-    "qtts_burst_build": (_i, [_p, _p, _sz, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p]),
-    "qtts_burst_launch": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _i, _u64, _p, _i, _p]),
-    "qtts_burst_status": (_i, [_p, _p, _i, _i]),
     "qtts_graph_begin": (_i, [_p]),
     "qtts_graph_end": (_p, [_p]),
     "qtts_graph_launch": (_i, [_p, _p]),
     "qtts_graph_destroy": (None, [_p]),
-    "qtts_tune_linear": (None, [_i, _i]),
-    "qtts_tune_subtiles": (None, [_i]),
-    "qtts_tune_prompt_attention": (None, [_i]),
-    "qtts_tune_rows": (None, [_i]),
-    "qtts_tune_shared_prologue": (None, [_i]),
-    "qtts_debug_linear": (None, [_i]),
-    "qtts_debug_linear_trace": (None, [_p]),
-    "qtts_debug_grid_barrier": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
 }
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)
     _fn.restype = _res
     _fn.argtypes = _args
 
-EXPORTED = [n for n in _SIGS if n not in ("qtts_tune_linear", "qtts_tune_subtiles", "qtts_tune_prompt_attention", "qtts_tune_rows", "qtts_tune_shared_prologue", "qtts_debug_linear", "qtts_debug_linear_trace", "qtts_debug_grid_barrier")]
+EXPORTED = list(_SIGS)
 
 
 class QttsError(RuntimeError):

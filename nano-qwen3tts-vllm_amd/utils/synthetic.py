@@ -118,9 +118,14 @@ def checkpoint_shapes(config: dict, with_text: bool = False) -> dict:
 
 
 def make_state_dict(config: dict, seed: int = 1234, norm_jitter: float = 0.0, std: float = 0.02,
-                    with_text: bool = False, embed_std: float | None = None) -> dict:
+                    with_text: bool = False, embed_std: float | None = None, head_sharp: float | None = None,
+                    head_std: float | None = None) -> dict:
     """bf16 tensors, N(0, std^2); norm weights 1 (+ jitter*N(0,1) when asked, so
-    that the bf16 `* weight` rounding step is exercised)."""
+    that the bf16 `* weight` rounding step is exercised).
+    head_std / head_sharp shape the output heads (`codec_head`, `lm_head.i`): rows N(0, head_std^2), each row then
+    scaled by exp(head_sharp * N(0,1)).  Random heads give logits whose two largest values are often a bf16 step
+    apart (greedy ids of such a model are decided by the last bit of a sum); log-normal row scales spread the top
+    of the distribution the way a trained head does, so that almost every greedy pick has a clear winner."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     for k, shp in checkpoint_shapes(config, with_text).items():
@@ -130,6 +135,10 @@ def make_state_dict(config: dict, seed: int = 1234, norm_jitter: float = 0.0, st
                 w = w + norm_jitter * torch.randn(shp, generator=g)
         elif "codec_embedding" in k and embed_std is not None:
             w = torch.randn(shp, generator=g) * embed_std
+        elif ("codec_head" in k or "lm_head" in k) and (head_sharp is not None or head_std is not None):
+            w = torch.randn(shp, generator=g) * (head_std if head_std is not None else std)
+            if head_sharp:
+                w = w * torch.exp(head_sharp * torch.randn(shp[0], 1, generator=g))
         else:
             w = torch.randn(shp, generator=g) * std
         sd[k] = w.to(torch.bfloat16)

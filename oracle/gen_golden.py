@@ -43,12 +43,15 @@ def f32(t):
     return t.detach().float().cpu().numpy()
 
 
-def build_models(ref, syn, size, seed):
+SHARP = dict(head_sharp=1.0, head_std=0.05)     # heads whose greedy picks have clear winners (synthetic.make_state_dict)
+
+
+def build_models(ref, syn, size, seed, **sd_kw):
     cfgmod = importlib.import_module("nano_qwen3tts_vllm.config")
     talker_mod = importlib.import_module("nano_qwen3tts_vllm.models.qwen3_tts_talker")
     pred_mod = importlib.import_module("nano_qwen3tts_vllm.models.qwen3_tts_predictor")
     cfg = syn.make_config(size)
-    sd = syn.make_state_dict(cfg, seed=seed, norm_jitter=0.1, with_text=True, embed_std=0.05)
+    sd = syn.make_state_dict(cfg, seed=seed, norm_jitter=0.1, with_text=True, embed_std=0.05, **sd_kw)
     full = cfgmod.Qwen3TTSConfig(**json.loads(json.dumps(cfg)))
     torch.set_default_dtype(torch.bfloat16)      # as the runner does (base.py:55)
     talker = talker_mod.Qwen3TTSTalkerForCausalLM(full.talker_config)
@@ -115,9 +118,9 @@ def gen_ops(ref):
 
 
 @torch.inference_mode()
-def gen_models(ref, syn, size, seed, tag):
+def gen_models(ref, syn, size, seed, tag, **sd_kw):
     ctx = importlib.import_module("nano_qwen3tts_vllm.utils.context")
-    cfg, sd, talker, pred = build_models(ref, syn, size, seed)
+    cfg, sd, talker, pred = build_models(ref, syn, size, seed, **sd_kw)
     t = cfg["talker_config"]
     p = t["code_predictor_config"]
     H = t["hidden_size"]
@@ -222,7 +225,10 @@ def gen_models(ref, syn, size, seed, tag):
     num_tokens = [L + 1 for L in lens]
     frames = np.zeros((S, NF, 16), dtype=np.int64)
     margins = np.zeros((S, NF), dtype=np.float32)
+    f_t_logits, f_p_logits, f_hidden = [], [], []
     for f in range(NF):
+        f_t_logits.append(f32(lg))
+        f_hidden.append(f32(hl))
         top2 = torch.topk(lg.float(), 2, dim=-1)[0]
         margins[:, f] = (top2[:, 0] - top2[:, 1]).numpy()
         tok0 = torch.argmax(lg.float(), dim=-1)
@@ -238,6 +244,7 @@ def gen_models(ref, syn, size, seed, tag):
         ctx.reset_context()
         tok = torch.argmax(plg.float(), dim=-1)
         ptoks = [tok.clone()]
+        plgs = [f32(plg)]
         n_tok = 3
         for step in range(1, 15):
             embeds = pred.get_input_embeddings(tok, None, [step] * S)
@@ -249,8 +256,10 @@ def gen_models(ref, syn, size, seed, tag):
             ctx.reset_context()
             tok = torch.argmax(plg.float(), dim=-1)
             ptoks.append(tok.clone())
+            plgs.append(f32(plg))
             n_tok += 1
         ptoks = torch.stack(ptoks, 1)
+        f_p_logits.append(np.stack(plgs, 1))
         nxt = []
         for i in range(S):
             frames[i, f, 0] = int(tok0[i])
@@ -271,7 +280,8 @@ def gen_models(ref, syn, size, seed, tag):
             num_tokens = [n + 1 for n in num_tokens]
     for i, pr in enumerate(prompts):
         out[f"f_prompt{i}"] = pr.numpy()
-    out.update(f_text_adds=text_adds.numpy(), f_frames=frames, f_margins=margins)
+    out.update(f_text_adds=text_adds.numpy(), f_frames=frames, f_margins=margins,
+               f_t_logits=np.stack(f_t_logits, 1), f_p_logits=np.stack(f_p_logits, 1), f_hidden=np.stack(f_hidden, 1))
     np.savez_compressed(os.path.join(OUT, f"model_{tag}.npz"), **out)
     print(f"model_{tag}.npz", frames[0, :, :4].tolist(), "min margin", margins.min())
 
@@ -343,6 +353,8 @@ def main():
     gen_ops(ref)
     gen_models(ref, syn, "tiny", 11, "tiny")
     gen_models(ref, syn, "tiny-id", 12, "tiny_id")
+    gen_models(ref, syn, "tiny", 13, "sharp", **SHARP)
+    gen_models(ref, syn, "tiny-id", 14, "sharp_id", **SHARP)
     gen_sched(ref)
     gen_protocol(ref)
     gen_frontend(ref, syn)

@@ -102,6 +102,14 @@ def store_kvcache(k, v, k_cache, v_cache, slot_mapping):
             vc[s] = v[i]
 
 
+# How the probabilities enter the P.V product.  None: fp32 softmax, fp32 product (the textbook definition, the
+# default and what the fixtures were generated with).  torch.bfloat16: the FlashAttention-2 forward as published
+# (Dao 2023, Algorithm 1; the flash_attn wheel the reference calls, P/layers/attention.py:88-95, is absent here):
+# unnormalised exp(s - max) rounded to the input dtype before the product with V, fp32 accumulation, division by the
+# fp32 row sum of the unrounded values at the end.  Switched by tests that quantify the difference between the two.
+ATTN_P_DTYPE = None
+
+
 def _attend(q, k, v, scale, causal_offset):
     Lq, Hq, D = q.shape
     Lk, Hkv, _ = k.shape
@@ -113,6 +121,10 @@ def _attend(q, k, v, scale, causal_offset):
     iq = torch.arange(Lq).unsqueeze(1) + causal_offset
     ik = torch.arange(Lk).unsqueeze(0)
     s = s.masked_fill(ik > iq, float("-inf"))
+    if ATTN_P_DTYPE is not None:
+        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        o = torch.matmul(e.to(ATTN_P_DTYPE).float(), vf) / e.sum(dim=-1, keepdim=True)
+        return o.transpose(0, 1).to(q.dtype)
     p = torch.softmax(s, dim=-1)
     return torch.matmul(p, vf).transpose(0, 1).to(q.dtype)
 
@@ -318,8 +330,10 @@ class OraclePredictor:
         self.w, self.cfg = w, cfg
         self.pages = _Paged(cfg, num_blocks)
 
-    def burst(self, embeds_list, return_logits=False):
-        """embeds_list: list of [2,H_talker]. Returns list of 15-token lists."""
+    def burst(self, embeds_list, return_logits=False, forced=None):
+        """embeds_list: list of [2,H_talker]. Returns list of 15-token lists.
+        forced [B][15] (optional): the ids fed back instead of the arg-max of each step (teacher forcing: the
+        logits of every step are then those of a caller-chosen history); the returned ids are still the arg-max."""
         B = len(embeds_list)
         n_gen = self.cfg.num_code_groups - 1
         seqs, xs, pos, slots, cu = [], [], [], [], [0]
@@ -340,6 +354,8 @@ class OraclePredictor:
         all_logits = [logits]
         tok = greedy(logits)
         out = [[int(t)] for t in tok]
+        if forced is not None:
+            tok = torch.tensor([int(f[0]) for f in forced])
         for s in seqs:
             s.num_tokens += 1
         for step in range(1, n_gen):
@@ -357,6 +373,8 @@ class OraclePredictor:
             tok = greedy(logits)
             for i, t in enumerate(tok):
                 out[i].append(int(t))
+            if forced is not None:
+                tok = torch.tensor([int(f[step]) for f in forced])
             for s in seqs:
                 s.num_tokens += 1
         for s in seqs:
@@ -376,37 +394,105 @@ def frame_glue(tw, pw, token0, pred_tokens, text_add):
     return s + text_add
 
 
-def frame_loop(tw, tcfg, pw, pcfg, prompts, text_adds, n_frames, num_blocks=32):
-    """Greedy generation of `n_frames` 16-code frames for each prompt, all streams
-    in one batch (the dead in-process loop P/interface.py:1322-1366 is the shape).
-    prompts: list of [L,H] tensors; text_adds: fp32 [S, n_frames, H] (what the API
-    process adds per step: trailing text hidden or the tts pad embedding).
-    Returns frames [S, n_frames, 16] (int64), the top-2 margin of the talker logits per frame, and
-    the smallest top-2 margin over all 16 picks of the frame (a pick whose margin is a bf16 ulp or
-    less may flip under a different fp32 summation order)."""
+def frame_loop_logits(tw, tcfg, pw, pcfg, prompts, text_adds, n_frames, forced=None, num_blocks=32):
+    """The frame loop of P/interface.py:1241-1290 (in-process shape: :1322-1366), greedy, all streams in one batch,
+    keeping the logits of every pick.  prompts: list of [L,H]; text_adds fp32 [S, n_frames, H] (what the API adds per
+    frame: trailing text hidden or the tts pad embedding).
+    forced [S, n_frames, 16] (optional): the ids that are FED ON (to the predictor's next step, the glue, the
+    talker's next input) instead of each pick's arg-max, so the logits of every pick are those of a caller-chosen
+    history — the way a run of the HIP path is checked pick by pick without a near-tie hiding what follows.
+    Returns dict: frames [S,NF,16] int64 (the arg-max of each pick), t_logits [S,NF,V], p_logits [S,NF,15,Vp],
+    hidden [S,NF,H] (the talker hidden state that opens each frame), all float32."""
     talker = OracleTalker(tw, tcfg, num_blocks)
     pred = OraclePredictor(pw, pcfg, num_blocks)
     S = len(prompts)
     frames = torch.zeros(S, n_frames, 16, dtype=torch.int64)
-    margins = torch.zeros(S, n_frames)
-    pick_margins = torch.zeros(S, n_frames)
+    t_logits, p_logits, hidden = [], [], []
     seqs, tok, hid, logits = talker.prefill(prompts)
     for f in range(n_frames):
-        top2 = torch.topk(logits.float(), 2, dim=-1)[0]
-        margins[:, f] = top2[:, 0] - top2[:, 1]
-        emb0 = tw["model.codec_embedding.weight"][torch.tensor(tok)].float()
+        t_logits.append(logits.float())
+        hidden.append(hid.float())
+        frames[:, f, 0] = torch.tensor(tok)
+        fed0 = [int(forced[i][f][0]) for i in range(S)] if forced is not None else [int(t) for t in tok]
+        emb0 = tw["model.codec_embedding.weight"][torch.tensor(fed0)].float()
         pin = [torch.stack([hid[i].float(), emb0[i]], 0) for i in range(S)]
-        ptoks, plogits = pred.burst(pin, return_logits=True)
-        pm = torch.stack([(lambda t2: t2[:, 0] - t2[:, 1])(torch.topk(l.float(), 2, dim=-1)[0]) for l in plogits], 1)
-        pick_margins[:, f] = torch.minimum(margins[:, f], pm.min(dim=1)[0])
+        fp = [[int(v) for v in forced[i][f][1:]] for i in range(S)] if forced is not None else None
+        ptoks, plogits = pred.burst(pin, return_logits=True, forced=fp)
+        p_logits.append(torch.stack([l.float() for l in plogits], 1))
         nxt = []
         for i in range(S):
-            frames[i, f, 0] = tok[i]
             frames[i, f, 1:] = torch.tensor(ptoks[i])
-            nxt.append(frame_glue(tw, pw, tok[i], ptoks[i], text_adds[i, f]))
+            fed = fp[i] if fp is not None else ptoks[i]
+            nxt.append(frame_glue(tw, pw, fed0[i], fed, text_adds[i, f]))
         if f + 1 < n_frames:
             tok, hid, logits = talker.decode(seqs, torch.stack(nxt, 0))
-    return frames, margins, pick_margins
+    return dict(frames=frames, t_logits=torch.stack(t_logits, 1), p_logits=torch.stack(p_logits, 1),
+                hidden=torch.stack(hidden, 1))
+
+
+def frame_loop(tw, tcfg, pw, pcfg, prompts, text_adds, n_frames, num_blocks=32):
+    """frame_loop_logits reduced to (frames [S,NF,16], top-2 margin of the talker logits per frame, smallest top-2
+    margin over the 16 picks of the frame)."""
+    r = frame_loop_logits(tw, tcfg, pw, pcfg, prompts, text_adds, n_frames, None, num_blocks)
+    t2 = torch.topk(r["t_logits"], 2, dim=-1)[0]
+    margins = t2[..., 0] - t2[..., 1]
+    p2 = torch.topk(r["p_logits"], 2, dim=-1)[0]
+    pick_margins = torch.minimum(margins, (p2[..., 0] - p2[..., 1]).min(dim=-1)[0])
+    return r["frames"], margins, pick_margins
+
+
+class other_summation_order:
+    """Context manager: every F.linear of this file runs with another fp32 summation order (K in four chunks, each
+    summed in fp32, the chunks added in fp32, one rounding to bf16 at the same point).  The arithmetic and its
+    rounding points are unchanged, so the distance between a run under it and a plain run is the noise floor any
+    second implementation of the reference's arithmetic sits on (28 layers deep it reaches several bf16 steps): the
+    yardstick for the HIP path at full model size."""
+
+    def __enter__(self):
+        import types
+
+        real = globals()["F"]
+
+        def linear(x, w, b=None):
+            c = max(x.shape[-1] // 4, 1)
+            acc = None
+            for i in range(0, x.shape[-1], c):
+                part = real.linear(x[..., i:i + c].float(), w[:, i:i + c].float())
+                acc = part if acc is None else acc + part
+            if b is not None:
+                acc = acc + b.float()
+            return acc.to(x.dtype)
+
+        self._saved = real
+        globals()["F"] = types.SimpleNamespace(linear=linear, silu=real.silu)
+        return self
+
+    def __exit__(self, *exc):
+        globals()["F"] = self._saved
+        return False
+
+
+def bf16_ulp(x: torch.Tensor) -> torch.Tensor:
+    """Spacing of bf16 numbers at |x| (8 significant bits): 2^(floor(log2|x|) - 7); the smallest normal's for 0."""
+    a = x.float().abs().clamp_min(2.0 ** -126)
+    return torch.exp2(torch.floor(torch.log2(a)) - 7)
+
+
+def judge_picks(ids: torch.Tensor, logits: torch.Tensor, tol_ulps: float = 2.0):
+    """How greedy picks made by another implementation of the same arithmetic stand against this file's logits of
+    the same history.  ids [...], logits [..., V] (bf16 values).  A pick is
+      acceptable  when its logit is within tol_ulps bf16 steps (at the size of the row's largest logit) of the
+                  largest — it is the arg-max, or a value that a last-bit difference of two fp32 summation orders
+                  can lift to a tie with it;
+      binding     when the runner-up is farther than that below the largest: then only the arg-max is acceptable.
+    Returns (acceptable [...], binding [...], equal-to-arg-max [...]) as bool tensors."""
+    lg = logits.float()
+    top2 = torch.topk(lg, 2, dim=-1)[0]
+    tol = tol_ulps * bf16_ulp(top2[..., 0])
+    chosen = torch.gather(lg, -1, ids.long().unsqueeze(-1)).squeeze(-1)
+    acceptable = (top2[..., 0] - chosen) <= tol
+    binding = (top2[..., 0] - top2[..., 1]) > tol
+    return acceptable, binding, ids.long() == torch.argmax(lg, dim=-1)
 
 
 def quantize_fp8_rows(w: torch.Tensor):

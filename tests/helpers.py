@@ -17,10 +17,23 @@ def bf(a):
     return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(torch.bfloat16)
 
 
-def golden_weights(size, seed):
+SHARP = dict(head_sharp=1.0, head_std=0.05)     # as oracle/gen_golden.py: heads whose greedy picks have clear winners
+
+# fixture tag -> (model size, weight seed, extra make_state_dict arguments), as oracle/gen_golden.py::main
+FIXTURES = {"tiny": ("tiny", 11, {}), "tiny_id": ("tiny-id", 12, {}), "sharp": ("tiny", 13, SHARP),
+            "sharp_id": ("tiny-id", 14, SHARP)}
+
+
+def fixture_model(tag):
+    """(config, state dict, talker weights, predictor weights, fixture arrays) of a golden model family."""
+    size, seed, kw = FIXTURES[tag]
+    return (*golden_weights(size, seed, **kw), load_npz(f"model_{tag}.npz"))
+
+
+def golden_weights(size, seed, **kw):
     """The same seeded synthetic checkpoint oracle/gen_golden.py loaded into the reference."""
     cfg = synthetic.make_config(size)
-    sd = synthetic.make_state_dict(cfg, seed=seed, norm_jitter=0.1, with_text=True, embed_std=0.05)
+    sd = synthetic.make_state_dict(cfg, seed=seed, norm_jitter=0.1, with_text=True, embed_std=0.05, **kw)
     tw, pw = synthetic.split_state_dict(sd)
     return cfg, sd, tw, pw
 
@@ -39,3 +52,45 @@ def oracle_cfgs(cfg):
                       p["head_dim"], p["intermediate_size"], p["vocab_size"], p["rms_norm_eps"], p["rope_theta"],
                       talker_hidden_size=t["hidden_size"], num_code_groups=p["num_code_groups"])
     return tc, pc
+
+
+# ---------------------------------------------------------------- pick-by-pick id parity
+def ulp_distance(got, want):
+    """|got - want| in bf16 steps at the size of the largest |want| of each row (last axis)."""
+    import qtts_oracle as O
+    got, want = torch.as_tensor(got).float().cpu(), torch.as_tensor(want).float().cpu()
+    return (got - want).abs() / O.bf16_ulp(want.abs().amax(dim=-1, keepdim=True))
+
+
+def check_frames(got, tw, tc, pw, pc, prompts, text_adds, what, tol_ulps=2.0, min_binding=0.9, fixture_frames=None,
+                 max_unacceptable=0, oracle_result=None):
+    """got [S,NF,16]: ids a HIP run produced.  The oracle replays the run with those ids fed on (teacher forcing), so
+    every one of the S*NF*16 picks is judged against the oracle's logits of the same history: it must be the arg-max,
+    or within tol_ulps bf16 steps of it (helpers of qtts_oracle.judge_picks).  No pick is skipped and an early
+    near-tie hides nothing that follows.  Asserts that at least min_binding of the picks had a clear winner (only the
+    arg-max acceptable).  Returns the oracle's result dict (logits of every pick) for further comparisons."""
+    import qtts_oracle as O
+    got = torch.as_tensor(got).long().cpu()
+    S, NF = got.shape[:2]
+    r = oracle_result or O.frame_loop_logits(tw, tc, pw, pc, prompts, text_adds, NF, forced=got)
+    a0, b0, e0 = O.judge_picks(got[..., 0], r["t_logits"], tol_ulps)
+    a1, b1, e1 = O.judge_picks(got[..., 1:], r["p_logits"], tol_ulps)
+    acc = torch.cat([a0.unsqueeze(-1), a1], -1)
+    bind = torch.cat([b0.unsqueeze(-1), b1], -1)
+    same = torch.cat([e0.unsqueeze(-1), e1], -1)
+    n = acc.numel()
+    line = (f"[id parity] {what}: {n} picks, {int(bind.sum())} binding ({100.0 * int(bind.sum()) / n:.1f} %), "
+            f"{int((~same).sum())} differ from the oracle's arg-max, {int((~acc).sum())} unacceptable")
+    if fixture_frames is not None:
+        line += f"; {int((got.numpy() == np.asarray(fixture_frames)).all(-1).sum())} of {S * NF} frames equal the reference fixture"
+    print(line)
+    bad = (~acc).nonzero().tolist()
+    if bad:                                  # how far off: the chosen id's logit below the oracle's largest, in bf16 steps
+        for (i, f, c) in bad[:8]:
+            row = r["t_logits"][i, f] if c == 0 else r["p_logits"][i, f, c - 1]
+            top = float(row.max())
+            print(f"  pick (stream {i}, frame {f}, code {c}): id {int(got[i, f, c])} has logit {float(row[got[i, f, c]]):.4f}, "
+                  f"the oracle's largest is {top:.4f} (id {int(row.argmax())}): {(top - float(row[got[i, f, c]])) / float(O.bf16_ulp(torch.tensor(top))):.1f} bf16 steps")
+    assert len(bad) <= max_unacceptable, f"{what}: picks {bad[:8]} are not the oracle's arg-max nor within {tol_ulps} bf16 steps of it"
+    assert int(bind.sum()) >= min_binding * n, f"{what}: only {int(bind.sum())} of {n} picks were binding"
+    return r

@@ -187,11 +187,13 @@ def test_paged_attention_decode(hip, Hq, Hkv, ctxs):
 
 
 @pytest.mark.parametrize("Hq,Hkv,lens", [(4, 2, [5, 140]), (16, 8, [200]), (2, 2, [33, 17, 300]), (4, 2, [16, 16, 7, 1, 1, 30, 2]),
-                                         (16, 8, [600]), (4, 2, [12]), (8, 4, [257, 31])])
+                                         (16, 8, [600]), (4, 2, [12]), (8, 4, [257, 31]), (4, 2, [16, 16, 7, 1, 1, 30, 2, 45, 3]),
+                                         (16, 8, [48]), (8, 8, [100, 11]), (4, 1, [130])])
 def test_paged_attention_prefill_rows(hip, Hq, Hkv, lens):
     """Causal prefill expressed as per-token rows over the just-stored cache equals
     the packed varlen formulation (P/layers/attention.py:88-91): single and several prompts per launch, row tiles
-    that straddle prompts, contexts over several KV blocks, both head ratios of the MFMA kernel and (12 rows) the
+    that straddle prompts, contexts over several KV blocks.  From 112 rows a launch takes the MFMA kernel (both of its
+    head ratios and ragged packed prompts are among the cases), below that and with four query heads per KV head the
     per-row kernel."""
     g = torch.Generator().manual_seed(3 + sum(lens))
     N = sum(lens)
@@ -214,16 +216,10 @@ def test_paged_attention_prefill_rows(hip, Hq, Hkv, lens):
             row_seq.append(s)
             ctx.append(t + 1)
     O.store_kvcache(k, v, kc, vc, torch.tensor(slots))
-    # both kernels at every size: the MFMA kernel from 17 rows, then the per-row kernel only
-    for min_rows in (17, 1 << 30):
-        hip.lib.qtts_tune_prompt_attention(min_rows)
-        try:
-            got = hip.paged_attention(q.reshape(N, -1).to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV),
-                                      torch.tensor(ctx, dtype=torch.int32, device=DEV), max(lens), 128 ** -0.5, Hq, Hkv,
-                                      row_seq=torch.tensor(row_seq, dtype=torch.int32, device=DEV))
-        finally:
-            hip.lib.qtts_tune_prompt_attention(112)
-        assert torch.allclose(got.float().cpu().view(N, Hq, 128), want.float(), atol=1e-2, rtol=2e-2), min_rows
+    got = hip.paged_attention(q.reshape(N, -1).to(DEV), kc.to(DEV), vc.to(DEV), bt.to(DEV),
+                              torch.tensor(ctx, dtype=torch.int32, device=DEV), max(lens), 128 ** -0.5, Hq, Hkv,
+                              row_seq=torch.tensor(row_seq, dtype=torch.int32, device=DEV))
+    torch.cuda.synchronize()
     assert torch.allclose(got.float().cpu().view(N, Hq, 128), want.float(), atol=1e-2, rtol=2e-2)
 
 
@@ -529,23 +525,18 @@ def test_linear_fp8_equals_bf16_on_dequantised_weights(hip, M, N, K, kind):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("M,N,K", [(17, 2048, 2048), (32, 4096, 1024), (24, 1024, 3072), (32, 2048, 6144)])
-def test_prompt_gemm_with_two_row_tiles(hip, M, N, K):
-    """17..32 rows take single-tile workgroups by default; the prompt GEMM's two-row-tile form stays available
-    (qtts_tune_rows) and agrees with the oracle as well."""
+@pytest.mark.parametrize("M,N,K", [(33, 2048, 2048), (48, 4096, 1024), (40, 1024, 3072), (64, 2048, 6144), (100, 1024, 3072)])
+def test_prompt_gemm_row_group_forms(hip, M, N, K):
+    """From 33 rows a GEMM takes the prompt kernel: row groups of four 16-row tiles, of two for K = 3072 (twelve
+    k-steps per wave), K = 6144 as K parts through the workspace; partial last tiles and groups."""
     g = torch.Generator().manual_seed(M * N + K)
     x = torch.randn(M, K, generator=g).bfloat16()
     w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
     wp = hip.pack_weight(w.to(DEV))
     want = torch.nn.functional.linear(x, w)
-    for min_rows in (16, 32):
-        hip.lib.qtts_tune_rows(min_rows)
-        try:
-            got = hip.linear_ws(x.to(DEV), wp, N)
-            torch.cuda.synchronize()
-        finally:
-            hip.lib.qtts_tune_rows(32)
-        assert_bf16_close(got, want, what=f"rows from {min_rows + 1}")
+    got = hip.linear_ws(x.to(DEV), wp, N)
+    torch.cuda.synchronize()
+    assert_bf16_close(got, want, what=f"prompt GEMM {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("N,K,kind", [(4096, 1024, "norm"), (4096, 2048, "norm"), (2048, 2048, "res"), (1024, 3072, "res"),
@@ -572,3 +563,141 @@ def test_rows_do_not_depend_on_the_row_count_form(hip, N, K, kind):
         part = run(rows)
         torch.cuda.synchronize()
         assert torch.equal(part, full[:rows]), f"{kind} {N}x{K}: {rows} rows differ from the 16-row launch"
+
+
+# ---------------------------------------------------------------- per-frame glue kept on the device
+def _glue_tables(V=512, Vp=256, H=256, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    tw = {"model.codec_embedding.weight": (torch.randn(V, H, generator=g) * 0.05).bfloat16()}
+    pw = {f"model.codec_embedding.{i}.weight": (torch.randn(Vp, H, generator=g) * 0.05).bfloat16() for i in range(15)}
+    return tw, pw, g
+
+
+@pytest.mark.parametrize("B,H", [(1, 256), (5, 256), (8, 2048), (16, 1024)])
+def test_frame_glue_bit_exact(hip, B, H):
+    """qtts_frame_glue against the oracle's glue (P/interface.py:1276-1285: the 16 codebook embeddings summed in fp32,
+    plus the frame's text / pad hidden, rounded to bf16 once when the talker takes it): bit for bit, with the ids
+    laid out as the burst leaves them (step-major, leading dimension larger than B), per-row frame indices into the
+    text table, and the 16 ids written out per row."""
+    V, Vp, F, ldp = 512, 256, 7, B + 3
+    tw, pw, g = _glue_tables(V, Vp, H, seed=B + H)
+    tok0 = torch.randint(0, V, (B,), generator=g)
+    pred = torch.randint(0, Vp, (15, ldp), generator=g)
+    text = torch.randn(B, F, H, generator=g) * 0.3
+    fidx = torch.randint(0, F, (B,), generator=g).to(torch.int32)
+    want = torch.stack([O.frame_glue(tw, pw, int(tok0[b]), [int(pred[c, b]) for c in range(15)], text[b, int(fidx[b])])
+                        for b in range(B)]).to(torch.bfloat16)
+    temb = tw["model.codec_embedding.weight"].to(DEV)
+    tabs = [pw[f"model.codec_embedding.{i}.weight"].to(DEV) for i in range(15)]
+    ptrs = torch.tensor([t.data_ptr() for t in tabs], dtype=torch.int64, device=DEV)
+    nxt = torch.zeros(B, H, dtype=torch.bfloat16, device=DEV)
+    codes = torch.full((B, 16), -1, dtype=torch.int64, device=DEV)
+    tok0d, predd, textd, fidxd = tok0.to(DEV), pred.to(DEV).contiguous(), text.to(DEV).contiguous(), fidx.to(DEV)
+    hip.check(hip.lib.qtts_frame_glue(hip.ptr(temb), hip.ptr(ptrs), hip.ptr(tok0d), hip.ptr(predd), ldp, hip.ptr(textd),
+                                      F * H, hip.ptr(fidxd), hip.ptr(nxt), hip.ptr(codes), B, H, V, Vp, hip.stream()), "frame_glue")
+    torch.cuda.synchronize()
+    assert torch.equal(nxt.cpu(), want)
+    assert torch.equal(codes.cpu(), torch.cat([tok0[:, None], pred[:, :B].t()], 1))
+    # without frame indices the first text row is used
+    hip.check(hip.lib.qtts_frame_glue(hip.ptr(temb), hip.ptr(ptrs), hip.ptr(tok0d), hip.ptr(predd), ldp, hip.ptr(textd),
+                                      F * H, None, hip.ptr(nxt), None, B, H, V, Vp, hip.stream()), "frame_glue")
+    torch.cuda.synchronize()
+    want0 = torch.stack([O.frame_glue(tw, pw, int(tok0[b]), [int(pred[c, b]) for c in range(15)], text[b, 0])
+                         for b in range(B)]).to(torch.bfloat16)
+    assert torch.equal(nxt.cpu(), want0)
+
+
+def test_predictor_input_rows(hip):
+    """qtts_predictor_input: row pair b = [talker hidden state of b ; codec_embedding(first code of b)]
+    (P/interface.py:1242-1252), bit for bit."""
+    B, H, V = 6, 256, 512
+    tw, _, g = _glue_tables(V, 256, H, seed=9)
+    hidden = torch.randn(B, H, generator=g).bfloat16()
+    tok0 = torch.randint(0, V, (B,), generator=g)
+    want = torch.stack([torch.stack([hidden[b], tw["model.codec_embedding.weight"][tok0[b]]]) for b in range(B)])
+    out = torch.zeros(B, 2, H, dtype=torch.bfloat16, device=DEV)
+    hd, td, ed = hidden.to(DEV), tok0.to(DEV), tw["model.codec_embedding.weight"].to(DEV)
+    hip.check(hip.lib.qtts_predictor_input(hip.ptr(hd), hip.ptr(ed), hip.ptr(td), hip.ptr(out), B, H, V, hip.stream()), "predictor_input")
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), want)
+
+
+def _host_decode_metadata(n, table):
+    """What the reference's prepare_decode_talker builds for a sequence of n tokens whose blocks are `table`
+    (P/engine/model_runner/talker_mode_runner.py:116-140 with P/engine/sequence.py:47-58): position = len(seq),
+    context = len(seq), slot = block_table[-1] * 256 + last_block_num_tokens - 1."""
+    num_blocks = (n + 255) // 256
+    last_block_num_tokens = n - (num_blocks - 1) * 256
+    return n, n, table[num_blocks - 1] * 256 + last_block_num_tokens - 1
+
+
+def test_advance_decode_follows_prepare_decode_talker(hip):
+    """qtts_advance_decode, called once per frame, walks the rows' metadata exactly as the reference rebuilds it on
+    the host for a sequence that grew by one token: across 256-token block boundaries, inactive rows (context 0)
+    untouched, rows frozen at max_context (1024) and at their own limit, frame index and RNG counter advanced."""
+    mb, B = 4, 8
+    g = torch.Generator().manual_seed(1)
+    tables = torch.stack([torch.randperm(40, generator=g)[:mb] for _ in range(B)]).to(torch.int32)
+    start = [0, 5, 254, 255, 510, 1021, 1023, 300]
+    limits = [1024, 1024, 1024, 1024, 1024, 1024, 1024, 303]
+    ctx = torch.tensor(start, dtype=torch.int32)
+    pos = ctx.to(torch.int64).clone()                  # the frame engine starts a row at (L, L) before the first advance
+    slots = torch.full((B,), -1, dtype=torch.int32)
+    fidx = torch.zeros(B, dtype=torch.int32)
+    d = dict(pos=pos.to(DEV), slots=slots.to(DEV), ctx=ctx.to(DEV), tab=tables.to(DEV).contiguous(), fidx=fidx.to(DEV),
+             rng=torch.zeros(1, dtype=torch.int64, device=DEV), lim=torch.tensor(limits, dtype=torch.int32, device=DEV))
+    n = list(start)
+    frames = [0] * B
+    for it in range(6):
+        hip.check(hip.lib.qtts_advance_decode(hip.ptr(d["pos"]), hip.ptr(d["slots"]), hip.ptr(d["ctx"]), hip.ptr(d["tab"]), mb,
+                                              hip.ptr(d["fidx"]), hip.ptr(d["rng"]), hip.ptr(d["lim"]), 1024, B, hip.stream()),
+                  "advance_decode")
+        torch.cuda.synchronize()
+        for b in range(B):
+            if n[b] > 0 and n[b] < min(limits[b], 1024):
+                n[b] += 1
+                frames[b] += 1
+        for b in range(B):
+            if n[b] == 0:
+                assert int(d["ctx"][b]) == 0 and int(d["slots"][b]) == -1 and int(d["fidx"][b]) == 0
+                continue
+            if frames[b] == 0:
+                continue                              # frozen from the start (context already at 1024 - no such row here)
+            wp, wc, ws = _host_decode_metadata(n[b], tables[b].tolist())
+            assert (int(d["pos"][b]), int(d["ctx"][b]), int(d["slots"][b])) == (wp, wc, ws), (it, b)
+            assert int(d["fidx"][b]) == frames[b]
+        assert int(d["rng"][0]) == 64 * (it + 1)
+    assert n == [0, 11, 260, 261, 516, 1024, 1024, 303]           # rows 5, 6 froze at 1024, row 7 at its own limit
+    # a null limit array means max_context alone
+    hip.check(hip.lib.qtts_advance_decode(hip.ptr(d["pos"]), hip.ptr(d["slots"]), hip.ptr(d["ctx"]), hip.ptr(d["tab"]), mb,
+                                          hip.ptr(d["fidx"]), None, None, 1024, B, hip.stream()), "advance_decode")
+    torch.cuda.synchronize()
+    assert int(d["ctx"][7]) == 304 and int(d["ctx"][6]) == 1024 and int(d["rng"][0]) == 64 * 6
+
+
+def test_decode_attention_with_a_context_beyond_the_launch(hip):
+    """A row whose device-side context length exceeds the max_context the host launched for is cut to it: its output
+    is written, and the arrival counters of the split merge are back at zero for the next launch."""
+    Hq, Hkv, B, maxc = 16, 8, 3, 256
+    g = torch.Generator().manual_seed(12)
+    kc = torch.randn(13, 256, Hkv, 128, generator=g).bfloat16().to(DEV)
+    vc = torch.randn(13, 256, Hkv, 128, generator=g).bfloat16().to(DEV)
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * 128, generator=g).bfloat16().to(DEV)
+    qw = torch.ones(128).bfloat16().to(DEV)
+    bt = (1 + torch.arange(12, dtype=torch.int32).reshape(3, 4)).to(DEV)
+    cl = torch.tensor([700, 200, 256], dtype=torch.int32, device=DEV)
+    pos = cl.to(torch.int64)
+    from nano_qwen3tts_vllm.models.hip_decoder import rope_tables
+    ct, st = (t.to(DEV) for t in rope_tables(128, 1000000.0, 2048))
+    nbytes = hip.lib.qtts_attn_decode_workspace_bytes(B, Hq, Hkv, 1024)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    out = torch.full((B, Hq * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    for _ in range(2):
+        hip.check(hip.lib.qtts_attention_decode_fused(hip.ptr(qkv), qkv.stride(0), hip.ptr(qw), hip.ptr(qw), 1e-6, hip.ptr(ct),
+                                                      hip.ptr(st), 2048, hip.ptr(pos), None, hip.ptr(kc), hip.ptr(vc), hip.ptr(bt),
+                                                      4, hip.ptr(cl), maxc, 128 ** -0.5, hip.ptr(out), Hq * 128, B, Hq, Hkv,
+                                                      hip.ptr(ws), hip.stream()), "attention_decode_fused")
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out.float()).all())
+    part = ((B * Hq * ((maxc + 127) // 128) * 130 * 4 + 255) // 256) * 256
+    assert int(ws[part:part + B * Hkv * 4].view(torch.int32).abs().sum()) == 0
