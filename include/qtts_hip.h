@@ -177,6 +177,21 @@ int qtts_attention_decode_fused(const void *qkv, int ldqkv, const void *q_norm_w
                                 const int32_t *context_lens, int max_context, float scale, void *out,
                                 int ldo, int B, int Hq, int Hkv, void *workspace, qtts_stream_t stream);
 
+/* qtts_attention_decode_fused for callers that cannot allocate (code under hipGraph capture that has no workspace
+ * to pass, tight serving loops, harnesses that forbid hipMalloc): the same kernels, same arguments and same results,
+ * but the split partials and arrival counters live in a static device array inside the library (about 1.02 MiB on
+ * every GPU the library runs on, held until the process ends) instead of a caller-provided workspace.  No
+ * counterpart in the reference.  Limits: B * Hq <= 256 and max_context <= 1024, larger calls are rejected with
+ * QTTS_EINVAL.  Calls no hipMalloc / hipFree; the first call on a device looks the array's address up (make it
+ * outside stream capture).  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams)
+ * race — serialise them, or use the workspace form. */
+int qtts_attention_decode_fused_static(const void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w,
+                                       float eps, const void *rope_cos, const void *rope_sin, int max_pos,
+                                       const int64_t *positions, const int32_t *slot_mapping, void *k_cache,
+                                       void *v_cache, const int32_t *block_tables, int max_blocks,
+                                       const int32_t *context_lens, int max_context, float scale, void *out,
+                                       int ldo, int B, int Hq, int Hkv, qtts_stream_t stream);
+
 /* Greedy pick: out[i] = argmax_j float(logits[i,j]), lowest j on ties (the build's
  * do_sample=False path; P/sampling_params.py:9 carries the flag). */
 int qtts_argmax(const void *logits, int ld, int64_t *out, int M, int V, qtts_stream_t stream);

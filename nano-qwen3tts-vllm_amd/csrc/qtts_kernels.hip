@@ -22,6 +22,7 @@
 #include <string.h>
 #include <math.h>
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -2161,6 +2162,68 @@ extern "C" int qtts_attention_decode_fused(const void *qkv, int ldqkv, const voi
     return attention_decode_fused_impl(qkv, ldqkv, q_norm_w, k_norm_w, eps, rope_cos, rope_sin, max_pos, positions,
                                        slot_mapping, k_cache, v_cache, block_tables, max_blocks, context_lens,
                                        max_context, scale, out, ldo, B, Hq, Hkv, workspace, counters, s);
+}
+
+// ---- the same entry point for callers that cannot allocate: the partials and counters live in a static device
+// array instead of a caller-provided workspace.  Each GPU holds its own copy of the array at its own address; host
+// code only ever uses the address hipGetSymbolAddress returns for the current device (the array's name is a
+// host-side stand-in, not a device address).
+#define QTTS_STATIC_ROWS_X_HEADS 256                 // B * Hq at most (e.g. 16 sequences x 16 query heads)
+#define QTTS_STATIC_MAX_CONTEXT 1024
+#define QTTS_STATIC_PARTIAL_BYTES ((size_t)QTTS_STATIC_ROWS_X_HEADS * (QTTS_STATIC_MAX_CONTEXT / ATT2_SPLIT) * (128 + 2) * sizeof(float))
+#define QTTS_STATIC_COUNTER_BYTES ((size_t)QTTS_STATIC_ROWS_X_HEADS * sizeof(int))       // B * Hkv <= B * Hq
+static __device__ __align__(256) unsigned char scratch[QTTS_STATIC_PARTIAL_BYTES + QTTS_STATIC_COUNTER_BYTES];
+
+#define QTTS_MAX_DEVICES 64
+static void *g_scratch_ptr[QTTS_MAX_DEVICES];        // per device: the address of that device's `scratch`
+static std::mutex g_scratch_mutex;
+
+// The current device's scratch array (looked up once per device, with that device current), or null + error text.
+static unsigned char *static_scratch_for_current_device() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= QTTS_MAX_DEVICES) {
+        snprintf(g_err, sizeof(g_err), "static scratch: no usable current device (%s)", hipGetErrorString(e));
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            snprintf(g_err, sizeof(g_err), "static scratch: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = ptr;
+    }
+    return (unsigned char *)g_scratch_ptr[dev];
+}
+
+extern "C" int qtts_attention_decode_fused_static(const void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w,
+                                                  float eps, const void *rope_cos, const void *rope_sin, int max_pos,
+                                                  const int64_t *positions, const int32_t *slot_mapping, void *k_cache,
+                                                  void *v_cache, const int32_t *block_tables, int max_blocks,
+                                                  const int32_t *context_lens, int max_context, float scale, void *out,
+                                                  int ldo, int B, int Hq, int Hkv, qtts_stream_t stream) {
+    QCHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "attention_decode_fused_static: bad shape");
+    QCHECK((long)B * Hq <= QTTS_STATIC_ROWS_X_HEADS,
+           "attention_decode_fused_static: B * Hq = %ld exceeds the static scratch's %d (use qtts_attention_decode_fused with a workspace)",
+           (long)B * Hq, QTTS_STATIC_ROWS_X_HEADS);
+    QCHECK(max_context > 0 && max_context <= QTTS_STATIC_MAX_CONTEXT,
+           "attention_decode_fused_static: max_context %d exceeds the static scratch's %d", max_context, QTTS_STATIC_MAX_CONTEXT);
+    unsigned char *ptr = static_scratch_for_current_device();
+    if (!ptr) return QTTS_ESTATE;
+    hipStream_t s = (hipStream_t)stream;
+    // the array keeps the previous call's contents: partials are written before they are read, the arrival counters
+    // must start at zero
+    int *counters = (int *)(ptr + QTTS_STATIC_PARTIAL_BYTES);
+    if (max_context > ATT2_SPLIT) {
+        hipError_t e = hipMemsetAsync(counters, 0, (size_t)B * Hkv * sizeof(int), s);
+        if (e != hipSuccess) QFAIL((int)e, "attention_decode_fused_static: memset failed: %s", hipGetErrorString(e));
+    }
+    return attention_decode_fused_impl(qkv, ldqkv, q_norm_w, k_norm_w, eps, rope_cos, rope_sin, max_pos, positions,
+                                       slot_mapping, k_cache, v_cache, block_tables, max_blocks, context_lens,
+                                       max_context, scale, out, ldo, B, Hq, Hkv, ptr, counters, s);
 }
 
 // ------------------------------------------------------------------ sampling

@@ -33,6 +33,8 @@ _SIGS = {
     "qtts_linear_fused": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _f, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "qtts_attention_decode_fused": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _f, _p, _i, _i,
                                          _i, _i, _p, _p]),
+    "qtts_attention_decode_fused_static": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _f, _p, _i, _i,
+                                                _i, _i, _p]),
     "qtts_model_forward_logits": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "qtts_model_forward_logits_pairs": (_i, [_p, _p, _p, _p, _i, _p, _p, _i, _p, _p]),
     "qtts_model_forward_logits_gathered": (_i, [_p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
