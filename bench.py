@@ -3,13 +3,15 @@
 Qwen3-TTS-12Hz-1.7B shapes (BASELINE.json configs[2]), synthetic weights and prompts.
 
     python bench.py --gpus 1 --steps 100 --warmup 10
+    python bench.py --gpus N ...                      (starts its N ranks itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step is one 16-code frame for every stream of this rank's replica (talker decode +
-15-step predictor burst + frame glue, one hipGraph).  Ranks are independent replicas
-(no collective on the data path); the barrier only brackets the timed region.
-Prefill of the prompts happens before the timed region and is reported separately
-as first-frame latency.  Rank 0 prints one JSON line.
+A step is one 16-code frame for every stream of this rank's replica (15-step predictor burst +
+frame glue as one hipGraph, talker decode as another).  Ranks are independent replicas (no
+collective on the data path; the barrier around the timed region is host-side).  `value` is the
+steady state with all streams admitted (prefill before the timed region, reported as first-chunk
+latency); `arrivals` in the same line is the serving form of the same configuration: streams
+arriving 50 ms apart, 125 frames each, prefill inside the timed region.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -80,40 +82,51 @@ def algorithmic_bytes_per_frame(cfg, B, mean_ctx, weights="bf16", folded=False):
     return 2 * talker + 2 * n_gen * pred_step + B * mean_ctx * kv_t + B * pred_ctx * kv_p - saved
 
 
-def time_dominant_kernel(fe, B, rounds=20):
-    """Average device time of the largest kernel of the path — the fused RMSNorm + gate/up GEMM +
-    SwiGLU launch of a talker layer — measured with HIP events on the engine's own stream, cycling
-    through all layers' weights so they come from HBM (28 x 50 MB >> the 256 MiB Infinity Cache)."""
-    from nano_qwen3tts_vllm import hip
+DOMINANT = "linear2_kernel<8,1,true,1> (talker RMSNorm + gate/up GEMM + SwiGLU launch)"
+
+
+def dominant_bytes(fe, B):
+    """Algorithmic bytes of one launch of the dominant kernel: the layer's gate/up weights once, the B input rows, the
+    norm weight and the B output rows."""
     tr = fe.tr
     H, I = tr.shape.hidden_size, tr.shape.intermediate_size
-    x = torch.randn(B, H, device=tr.device).to(torch.bfloat16)
-    out = torch.empty(B, I, dtype=torch.bfloat16, device=tr.device)
-    # packed gate/up tensors are the 2*I*H-element buffers the decoder keeps
-    packed = tr.decoder.packed_gate_up
     fp8 = tr.decoder.weight_dtype == "fp8"
-    scales = tr.decoder.gate_up_scales if fp8 else [None] * len(packed)
-    norm = tr.decoder.final_norm
-    assert len(packed) == tr.shape.num_layers
+    return 2 * I * H * (1 if fp8 else 2) + (2 * I * 4 if fp8 else 0) + B * H * 2 + B * I * 2
 
-    def launch(w, sc):
-        if fp8:
-            hip.linear_swiglu_fp8(x, w, sc, I, norm_w=norm, out=out)
-        else:
-            hip.linear_swiglu(x, w, I, norm_w=norm, out=out)
-    with fe.tr.on_stream():
-        for w, sc in zip(packed, scales):
-            launch(w, sc)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(rounds):
-            for w, sc in zip(packed, scales):
-                launch(w, sc)
-        e1.record()
-        e1.synchronize()
-    n = rounds * len(packed)
-    sec = e0.elapsed_time(e1) * 1e-3 / n
-    return sec, 2 * I * H * (1 if fp8 else 2) + (2 * I * 4 if fp8 else 0) + B * H * 2 + B * I * 2
+
+def time_dominant_kernel_in_frames(fe, frames=30):
+    """Device time of the path's largest kernel - the fused RMSNorm + gate/up GEMM + SwiGLU launch of a talker layer -
+    measured where it runs: while whole frames are generated (the codes graph, then the talker step's launches) that
+    launch of every layer carries two HIP events as its start / stop events on the engine's stream
+    (qtts_model_set_layer_events), whose elapsed time is the kernel's own execution time.  Returns (mean seconds, median seconds, samples).  The
+    timed region of the benchmark runs without the events; this pass follows it with the same streams."""
+    from nano_qwen3tts_vllm import hip
+    import ctypes
+    tr = fe.tr
+    nl = tr.shape.num_layers
+    begin = [torch.cuda.Event(enable_timing=True) for _ in range(nl)]
+    end = [torch.cuda.Event(enable_timing=True) for _ in range(nl)]
+    samples = []
+    bs = fe._bucket()
+    with tr.on_stream():
+        for e in begin + end:                       # an event's handle exists once it has been recorded
+            e.record()
+        arr = ctypes.c_void_p * nl
+        hip.check(hip.lib.qtts_model_set_layer_events(tr.decoder._h, 3, arr(*[e.cuda_event for e in begin]),
+                                                      arr(*[e.cuda_event for e in end])), "set_layer_events")
+        try:
+            fe._setup_predictor_meta(bs)
+            for f in range(frames):
+                fe._launch_codes(bs)
+                fe._talker_part(bs, fe._max_ctx_bucket(extra_frames=f + 1))      # eager launches, gate/up with events
+                tr.stream.synchronize()
+                if f >= 2:
+                    samples += [b.elapsed_time(e) * 1e-3 for b, e in zip(begin, end)]
+        finally:
+            hip.check(hip.lib.qtts_model_set_layer_events(tr.decoder._h, 0, None, None), "set_layer_events")
+    for s in fe.streams.values():                   # these frames advanced the streams' contexts like any others
+        s.frames.extend([[0] * 16] * frames)
+    return statistics.fmean(samples), statistics.median(samples), len(samples)
 
 
 def cpu_baseline(cfg, tw, pw, B, frames, prompt_len):
@@ -139,15 +152,16 @@ def cpu_baseline(cfg, tw, pw, B, frames, prompt_len):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE collected separately, FETCH_SIZE doubled as gfx950 requires); None when the file is absent.
-    Counters cannot be read from inside this process, so the figure is the one measured on the same kernel
-    and shape by tools/microbench.py dominant."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
-    except Exception:
-        return None
+    """HBM bytes per launch of the dominant kernel as stored in profiles/ by the rocprofv3 PMC passes over
+    tools/microbench.py dominant (FETCH_SIZE and WRITE_SIZE collected separately, FETCH_SIZE doubled as gfx950
+    requires) - a stored figure: hardware counters cannot be read from inside this process.  None when absent."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["traffic_bytes_per_launch"], f"profiles/{name}"
+        except Exception:
+            continue
+    return None, None
 
 
 def dist_env():
@@ -155,12 +169,12 @@ def dist_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def max_over_ranks(elapsed: float, world: int, device=None) -> float:
-    """Replicas are independent: the job's time is the slowest rank's."""
+def max_over_ranks(elapsed: float, world: int) -> float:
+    """Replicas are independent: the job's time is the slowest rank's (host-side reduction)."""
     if world <= 1:
         return elapsed
     import torch.distributed as dist
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -168,6 +182,106 @@ def max_over_ranks(elapsed: float, world: int, device=None) -> float:
 def whole_job_tokens(streams_per_gpu: int, steps: int, world: int) -> int:
     """16 codes per frame per stream, every rank runs `streams_per_gpu` streams for `steps` frames (weak scaling)."""
     return 16 * streams_per_gpu * steps * world
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_replicas(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start N copies of this script, one per GPU (rank i
+    on device i), before this process has touched a GPU, and wait for them.  Rank 0's JSON line goes to this
+    process's stdout.  A failed or killed child ends the others and the exit code is non-zero."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), QTTS_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in list(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in pending:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def percentile(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, int(round(q * (len(xs) - 1))))] if xs else None
+
+
+def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed):
+    """BASELINE.json configs[2] as a serving workload: `streams` requests arrive `gap_s` apart (prompt lengths cycling
+    through `lens`), each wants `frames` frames; admission and prefill happen inside the timed region, between two
+    frames of the running batch, as a server's loop does.  Returns throughput and latency statistics; the clock is
+    the host's (a frame is counted when its 16 codes are on the host)."""
+    from nano_qwen3tts_vllm.engine.frame_engine import NoCapacity
+    g = torch.Generator().manual_seed(seed)
+    reqs = []
+    for i in range(streams):
+        L = lens[i % len(lens)]
+        reqs.append((L, (torch.randn(L, H, generator=g) * 0.5).to(device), (torch.randn(frames + 1, H, generator=g) * 0.1).to(device)))
+    torch.cuda.synchronize()
+    arrival = [i * gap_s for i in range(streams)]
+    first, last, gaps, done_frames, sid_of = {}, {}, [], {}, {}
+    nxt = 0
+    t0 = time.perf_counter()
+    now = lambda: time.perf_counter() - t0
+    while len(done_frames) < streams or fe.streams:
+        while nxt < streams and now() >= arrival[nxt]:
+            L, prompt, text = reqs[nxt]
+            try:
+                sid = fe.add_stream(prompt, text, max_frames=frames, talker_sampling=samplers[0], predictor_sampling=samplers[1],
+                                    sid=f"arr-{nxt}")
+            except NoCapacity:
+                break                                  # admitted as soon as a running stream ends
+            sid_of[sid] = nxt
+            done_frames[nxt] = 0
+            nxt += 1
+        if not fe.streams:
+            if nxt >= streams:
+                break
+            time.sleep(max(0.0, min(arrival[nxt] - now(), 0.001)))
+            continue
+        res = fe.step()
+        t = now()
+        for sid in res:
+            i = sid_of[sid]
+            if done_frames[i] == 0:
+                first[i] = t - arrival[i]
+            else:
+                gaps.append(t - last[i])
+            last[i] = t
+            done_frames[i] += 1
+    elapsed = now()
+    total = sum(done_frames.values())
+    assert total == streams * frames, (done_frames, frames)
+    ms = lambda v: None if v is None else v * 1e3
+    return {"streams": streams, "arrival_gap_ms": gap_s * 1e3, "frames_per_stream": frames, "prompt_tokens": [r[0] for r in reqs],
+            "elapsed_s": elapsed, "codec_tokens_per_s": 16 * total / elapsed,
+            "rtf_per_stream_mean": statistics.fmean((last[i] - arrival[i]) / (frames * FRAME_SECONDS) for i in range(streams)),
+            "first_chunk_ms_p50": ms(percentile(list(first.values()), 0.5)), "first_chunk_ms_p99": ms(percentile(list(first.values()), 0.99)),
+            "inter_chunk_ms_p50": ms(percentile(gaps, 0.5)), "inter_chunk_ms_p99": ms(percentile(gaps, 0.99)),
+            "note": "prefill and admission inside the timed region; first chunk = arrival -> the stream's first 16-code frame on the host"}
+
+
+ROOFLINE_FRAMES = 30
+ARRIVAL_FRAMES = 125          # 10 s of audio per stream
+ARRIVAL_GAP_S = 0.050
 
 
 def main():
@@ -180,27 +294,30 @@ def main():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: the layers' GEMM weights as e4m3 with power-of-two row scales (an extension; not the contract line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-arrivals", action="store_true", help="skip the staggered-arrival serving workload")
     ap.add_argument("--cpu-frames", type=int, default=40)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one (nothing has touched a GPU yet)
+        sys.exit(launch_replicas(args.gpus))
 
     os.environ["QTTS_WEIGHT_DTYPE"] = args.weights
     rank, world, local = dist_env()
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    # Rehearsal on a box with fewer GPUs than ranks (QTTS_BENCH_REHEARSAL=1): every rank uses GPU 0 and the
-    # timing collectives run over gloo, since RCCL refuses two ranks on one device.  Never used for reported numbers.
+    # Rehearsal on a box with fewer GPUs than ranks (QTTS_BENCH_REHEARSAL=1): every rank uses GPU 0.  Never used for
+    # reported numbers.
     rehearsal = os.environ.get("QTTS_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    coll_device = None if rehearsal else device
     if world > 1:
+        # Replicas only: no collective touches the data path, and none touches a GPU - the barrier around the timed
+        # region and the max over ranks are host-side (gloo).
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("gloo")
 
     from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
     from nano_qwen3tts_vllm.sampling_params import SamplingParams
@@ -211,21 +328,22 @@ def main():
     mdir = tempfile.mkdtemp(prefix="qtts_bench_")
     json.dump(cfg, open(os.path.join(mdir, "config.json"), "w"))
     B = args.streams
-    n_frames = args.steps + args.warmup + 1
+    n_frames = args.steps + args.warmup + 1 + ROOFLINE_FRAMES
     H = cfg["talker_config"]["hidden_size"]
-    fe = FrameEngine(mdir, max_streams=B, max_text_frames=n_frames + 1, talker_weights=tw, predictor_weights=pw,
+    fe = FrameEngine(mdir, max_streams=B, max_text_frames=max(n_frames, ARRIVAL_FRAMES) + 2, talker_weights=tw, predictor_weights=pw,
                      num_kvcache_blocks=4 * B, max_num_batched_tokens=4096, codec_eos=None)
-    # as a server does at start-up (Qwen3TTSInterface.start_zmq_tasks): every frame graph this run can meet is captured
-    # before the first request, so first-chunk latency below is a replay, not a capture
-    fe.capture_all(max_context=min(1024, ((max(200, 0) + n_frames + 2 + 127) // 128) * 128))
-    greedy_t = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
-    greedy_p = SamplingParams(temperature=0.9, max_tokens=17, do_sample=False)
     lens = [16, 48, 128, 200]
     # a stream's prompt + frames must fit the model's 1024 positions: very long runs get shorter prompts
     room = 1024 - (n_frames + 4)
     if room < 8:
-        raise SystemExit(f"--steps + --warmup = {args.steps + args.warmup} frames do not fit 1024 positions per stream; use at most 1000")
-    lens = [min(L, room) for L in lens]
+        raise SystemExit(f"--steps + --warmup = {args.steps + args.warmup} frames do not fit 1024 positions per stream; use at most {1000 - ROOFLINE_FRAMES}")
+    steady_lens = [min(L, room) for L in lens]
+    # as a server does at start-up (Qwen3TTSInterface.start_zmq_tasks): every frame graph this run can meet is captured
+    # before the first request, so first-chunk latencies below are replays, not captures
+    top_ctx = max(max(steady_lens) + n_frames, max(lens) + ARRIVAL_FRAMES) + 3
+    fe.capture_all(max_context=min(1024, ((top_ctx + 127) // 128) * 128))
+    greedy_t = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
+    greedy_p = SamplingParams(temperature=0.9, max_tokens=17, do_sample=False)
     g = torch.Generator().manual_seed(1000 + rank)
     # one warm-up request per prompt-kernel family (the reference's server fires warm-up requests too, E/server.py:276)
     for L in (16, 200):
@@ -233,10 +351,19 @@ def main():
                             max_frames=4, talker_sampling=greedy_t, predictor_sampling=greedy_p)
         fe.run_frames(1)
         fe.remove_stream(sid)
+
+    # ---- the serving workload of configs[2]: staggered arrivals, prefill inside the timed region (rank-local, reported
+    # by rank 0 at N = 1 beside the contract number)
+    arrivals = None
+    if not args.no_arrivals and world == 1:
+        arrivals = run_arrivals(fe, device, H, B, ARRIVAL_FRAMES, ARRIVAL_GAP_S, lens, (greedy_t, greedy_p), 2000 + rank)
+        assert not fe.streams
+
+    # ---- the contract number: B streams admitted, steady-state frames
     first_frame_ms = []
     prompt_lens = []
     for i in range(B):
-        L = lens[i % len(lens)]
+        L = steady_lens[i % len(steady_lens)]
         prompt_lens.append(L)
         prompt = (torch.randn(L, H, generator=g) * 0.5).to(device)
         text = (torch.randn(n_frames + 1, H, generator=g) * 0.1).to(device)
@@ -266,7 +393,7 @@ def main():
     fe.run_frames(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, world, coll_device)
+    elapsed = max_over_ranks(elapsed, world)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -275,16 +402,21 @@ def main():
         mean_ctx = sum(prompt_lens) / B + 1 + args.warmup + 1 + args.steps / 2
         folded = bool(getattr(fe.pr, "fold", False)) and B <= 16
         bytes_frame = algorithmic_bytes_per_frame(cfg, B, mean_ctx, args.weights, folded)
-        ksec, kbytes = time_dominant_kernel(fe, B)
+        kmean, kmedian, ksamples = time_dominant_kernel_in_frames(fe, ROOFLINE_FRAMES)
+        kbytes = dominant_bytes(fe, B)
+        traffic, traffic_src = pmc_traffic() if args.weights == "bf16" and args.size == "1.7B" and B == 8 else (None, None)
         out = {
             "metric": "codec tokens/sec at 8 concurrent streams per GPU (RTF alongside), Qwen3-TTS-1.7B",
             "value": value, "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.weights == "bf16" else "bf16 (weights stored as fp8 e4m3, converted in registers)",
             "data": "synthetic",
-            "config": {"workload": f"Qwen3-TTS-12Hz-{args.size} shapes, {B} concurrent streams per GPU, greedy, "
-                                   f"continuous decode with one hipGraph per frame; prompts {prompt_lens} tokens, "
-                                   f"random-init weights" + (", fp8 weights" if args.weights == "fp8" else "") + (" [REHEARSAL: all ranks on one GPU]" if rehearsal else ""),
+            "config": {"workload": f"`value`: Qwen3-TTS-12Hz-{args.size} shapes, {B} concurrent streams per GPU all admitted, greedy, "
+                                   f"steady-state frames (one codes graph + one talker graph per frame), prompts {prompt_lens} "
+                                   f"tokens prefilled before the timed region, random-init weights"
+                                   + (", fp8 weights" if args.weights == "fp8" else "")
+                                   + (" [REHEARSAL: all ranks on one GPU]" if rehearsal else "")
+                                   + "; `arrivals`: the same engine under staggered arrivals with prefill inside the timed region",
                        "streams_per_gpu": B, "replicas": world},
             "rtf": ms_per_step * 1e-3 / FRAME_SECONDS,
             "first_chunk_ms_p50": statistics.median(first_frame_ms) + frame0_ms,
@@ -292,12 +424,16 @@ def main():
             "frame_roofline": {"bound": "hbm", "bytes_per_frame": bytes_frame,
                                "achieved": bytes_frame / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                "unit": "GB/s", "frac": bytes_frame / (ms_per_step * 1e-3) / HBM_PEAK},
-            "roofline": {"bound": "hbm", "kernel": "linear2_kernel<8,1,true,1> (talker RMSNorm + gate/up GEMM + SwiGLU launch)",
-                         "achieved": kbytes / ksec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": kbytes / ksec / HBM_PEAK, "traffic": pmc_traffic() if args.weights == "bf16" else None,
-                         "bytes_per_launch": kbytes,
-                         "us_per_launch": ksec * 1e6},
+            "roofline": {"bound": "hbm", "kernel": DOMINANT,
+                         "achieved": kbytes / kmean / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": kbytes / kmean / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                         "bytes_per_launch": kbytes, "us_per_launch": kmean * 1e6, "us_per_launch_median": kmedian * 1e6,
+                         "launches_timed": ksamples,
+                         "how": "HIP start/stop events bound to that launch of each of the 28 layers (hipExtLaunchKernelGGL on "
+                                "the engine's stream) while frames are generated, right after the timed region"},
         }
+        if arrivals is not None:
+            out["arrivals"] = arrivals
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed beside the 1-GPU line only
             out["cpu_baseline"] = cpu_baseline(cfg, tw, pw, B, args.cpu_frames, 16)
         print(json.dumps(out), flush=True)

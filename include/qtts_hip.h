@@ -269,6 +269,18 @@ int qtts_model_set_layer_fp8(qtts_model_t *m, int layer, const void *input_norm_
                              const void *w_down_fp8, const float *w_down_scales);
 
 int qtts_model_set_final_norm(qtts_model_t *m, const void *w);
+/* Measurement hook: from now on every decode step of `m` (up to 16 rows) launches GEMM number `which` of layer l with
+ * begin[l] / end[l] (hipEvent_t, n_layers of each, created by the caller with timing enabled; the arrays are copied)
+ * as the kernel's own start / stop events (hipExtLaunchKernelGGL), so hipEventElapsedTime(begin[l], end[l]) after
+ * the stream has drained is that kernel's execution time in place, between the launches it really follows and
+ * precedes - the figure a kernel trace reports for it.  which == 0 switches the hook off.  Not for forwards under
+ * stream capture.  The reference times whole steps with time.time() around run_model
+ * (P/engine/model_runner/talker_mode_runner.py:53,83-84); it has no per-launch figure. */
+#define QTTS_LAUNCH_QKV 1        /* input norm + q/k/v projection */
+#define QTTS_LAUNCH_O_PROJ 2     /* o_proj + residual */
+#define QTTS_LAUNCH_GATE_UP 3    /* post-attention norm + gate/up projection + SwiGLU */
+#define QTTS_LAUNCH_DOWN 4       /* down_proj + residual */
+int qtts_model_set_layer_events(qtts_model_t *m, int which, void *const *begin, void *const *end);
 int qtts_model_set_rope(qtts_model_t *m, const void *cos, const void *sin, int max_pos);
 /* kv: [2, n_layers, num_blocks, 256, n_kv_heads, 128] bf16 (P/engine/model_runner/base.py:158-164). */
 int qtts_model_set_kv_cache(qtts_model_t *m, void *kv, int num_blocks);

@@ -17,6 +17,7 @@
 //    combine pass.
 //  * Nothing here allocates or synchronises; everything is graph-capturable.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -866,6 +867,18 @@ __global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *par
     }
 }
 
+// Measurement hook (qtts_model_set_layer_events): when set, the next decode GEMM launch of this thread carries the
+// two events as the kernel's start / stop events.
+struct KernelEvents { hipEvent_t start, stop; };
+static thread_local KernelEvents g_kernel_events = {nullptr, nullptr};
+#define QTTS_LAUNCH_MAYBE_TIMED(kern, grid, block, shmem, s, ...) do { \
+        if (g_kernel_events.start) { \
+            hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)(shmem), s, g_kernel_events.start, g_kernel_events.stop, 0, __VA_ARGS__); \
+            g_kernel_events = {nullptr, nullptr}; \
+        } else { \
+            hipLaunchKernelGGL(kern, grid, block, shmem, s, __VA_ARGS__); \
+        } } while (0)
+
 template <int KSW, int PRO, bool DB, int EPI, bool SUB = false>
 static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs &a) {
     constexpr bool CAN_H8 = PRO != 2 && KSW % 2 == 0;
@@ -882,20 +895,20 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
     tl.wscale = a.wscale;
     if constexpr (KSW % 2 == 0 && PRO != 2) {
         if (a.wscale) {
-            hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI, SUB, true>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids,
-                               a.ldx, a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
+            QTTS_LAUNCH_MAYBE_TIMED((linear2_kernel<KSW, PRO, DB, EPI, SUB, true>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids,
+                                    a.ldx, a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
             return;
         }
     }
     if constexpr (CAN_H8) {
         if (a.M <= 8 && !(a.dbg >> 8) && g_share_prologue) {          // one row tile of at most 8 rows
-            hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI, SUB, false, true>), grid, dim3(NW * 64), shmem, s, a.x, a.wp,
-                               a.ids, a.ldx, a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
+            QTTS_LAUNCH_MAYBE_TIMED((linear2_kernel<KSW, PRO, DB, EPI, SUB, false, true>), grid, dim3(NW * 64), shmem, s, a.x, a.wp,
+                                    a.ids, a.ldx, a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
             return;
         }
     }
-    hipLaunchKernelGGL((linear2_kernel<KSW, PRO, DB, EPI, SUB>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids, a.ldx,
-                       a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
+    QTTS_LAUNCH_MAYBE_TIMED((linear2_kernel<KSW, PRO, DB, EPI, SUB>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids, a.ldx,
+                            a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
 }
 
 template <int KSW, int TM, int EPI>
@@ -2656,6 +2669,21 @@ struct qtts_model {
     char *ws = nullptr;
     size_t ws_bytes = 0;
     int ws_rows = 0, ws_ctx = 0;
+    // measurement hook (qtts_model_set_layer_events): events recorded around one launch of every layer
+    int ev_which = 0;
+    std::vector<hipEvent_t> ev_begin, ev_end;
+};
+
+// Hands the layer's begin / end event to the decode GEMM launcher for launch number `which` of the layer body when
+// the hook is set: the launch then goes through hipExtLaunchKernelGGL, which binds the two events to the kernel's
+// own start and end (the times a profiler reports for it).
+struct LayerEventScope {
+    bool on;
+    LayerEventScope(const qtts_model *m, int layer, int which, qtts_stream_t)
+        : on(m->ev_which == which && which != 0) {
+        if (on) g_kernel_events = {m->ev_begin[layer], m->ev_end[layer]};
+    }
+    ~LayerEventScope() { if (on) g_kernel_events = {nullptr, nullptr}; }    // (a launch that took another kernel)
 };
 
 extern "C" qtts_model_t *qtts_model_create(int hidden, int n_layers, int n_heads, int n_kv_heads, int head_dim,
@@ -2710,6 +2738,24 @@ extern "C" int qtts_model_set_layer_fp8(qtts_model_t *m, int layer, const void *
     if (rc) return rc;
     LayerW &L = m->layers[layer];
     L.s_qkv = wqkv_scales; L.s_o = wo_scales; L.s_gu = w_gate_up_scales; L.s_down = w_down_scales;
+    return QTTS_OK;
+}
+
+extern "C" int qtts_model_set_layer_events(qtts_model_t *m, int which, void *const *begin, void *const *end) {
+    QCHECK(m, "model_set_layer_events: null model");
+    QCHECK(which >= 0 && which <= QTTS_LAUNCH_DOWN, "model_set_layer_events: unknown launch %d", which);
+    QCHECK(which == 0 || (begin && end), "model_set_layer_events: null event arrays");
+    m->ev_which = 0;
+    m->ev_begin.clear();
+    m->ev_end.clear();
+    if (which) {
+        for (int l = 0; l < m->n_layers; ++l) {
+            QCHECK(begin[l] && end[l], "model_set_layer_events: null event for layer %d", l);
+            m->ev_begin.push_back((hipEvent_t)begin[l]);
+            m->ev_end.push_back((hipEvent_t)end[l]);
+        }
+        m->ev_which = which;
+    }
     return QTTS_OK;
 }
 
@@ -2845,8 +2891,11 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
                 return rc;
         } else if (l == 0 && qkv0_rows) {
             // layer 0's normalised, projected rows come from the table
-        } else if ((rc = stack_linear(cur, H, L.wqkv, L.s_qkv, nullptr, 0, L.in_norm, m->eps, qkv, qkvw, N, qkvw, H, nullptr, 0,
-                                      stream, nullptr, nullptr, 0, l == 0 ? x_ids : nullptr, nullptr, x_id_rows))) return rc;
+        } else {
+            LayerEventScope ev(m, l, QTTS_LAUNCH_QKV, stream);
+            if ((rc = stack_linear(cur, H, L.wqkv, L.s_qkv, nullptr, 0, L.in_norm, m->eps, qkv, qkvw, N, qkvw, H, nullptr, 0,
+                                   stream, nullptr, nullptr, 0, l == 0 ? x_ids : nullptr, nullptr, x_id_rows))) return rc;
+        }
         const bool tab0 = l == 0 && qkv0_rows;
         if (pairs) {
             if ((rc = attention_pairs_impl(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos, positions,
@@ -2864,17 +2913,24 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
             if ((rc = qtts_paged_attention(qkv, qkvw, kc, vc, block_tables, max_blocks, row_seq, context_lens,
                                            max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws, stream))) return rc;
         }
-        if ((rc = stack_linear(attn, Hq * 128, L.wo, L.s_o, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, nullptr, 0, stream,
-                               nullptr, nullptr, 0, nullptr, l == 0 ? x_ids : nullptr, x_id_rows)))
-            return rc;
+        {
+            LayerEventScope ev(m, l, QTTS_LAUNCH_O_PROJ, stream);
+            if ((rc = stack_linear(attn, Hq * 128, L.wo, L.s_o, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, nullptr, 0, stream,
+                                   nullptr, nullptr, 0, nullptr, l == 0 ? x_ids : nullptr, x_id_rows)))
+                return rc;
+        }
         if (split_norm) {
             if ((rc = qtts_rmsnorm(xa, H, L.post_norm, m->eps, xn, H, N, H, stream))) return rc;
             if ((rc = stack_swiglu(xn, H, L.wgu, L.s_gu, nullptr, 0.f, act, m->inter, N, m->inter, H, stream))) return rc;
-        } else if ((rc = stack_swiglu(xa, H, L.wgu, L.s_gu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
+        } else {
+            LayerEventScope ev(m, l, QTTS_LAUNCH_GATE_UP, stream);
+            if ((rc = stack_swiglu(xa, H, L.wgu, L.s_gu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
+        }
         // a prompt's K-split down_proj also normalises the finished rows for whoever reads them next: the next
         // layer's input norm, or the final norm (the returned hidden state)
         const bool last = l + 1 == m->n_layers;
         const bool fuse_next = split_norm && linear_rows_is_ksplit(N, H, m->inter, W.parts_bytes);
+        LayerEventScope ev_down(m, l, QTTS_LAUNCH_DOWN, stream);
         if ((rc = stack_linear(act, m->inter, L.wdown, L.s_down, xa, H, nullptr, fuse_next ? m->eps : 0.f, xb, H, N, H, m->inter,
                                (float *)(m->ws + W.parts), W.parts_bytes, stream,
                                fuse_next ? (last ? m->final_norm : m->layers[l + 1].in_norm) : nullptr,

@@ -41,8 +41,10 @@ class Stream:
 
 class FrameEngine:
     def __init__(self, model_dir: str, max_streams: int = 8, max_text_frames: int = 1024, talker_weights=None,
-                 predictor_weights=None, enforce_eager: bool = False, codec_eos: int | None = CODEC_EOS, **kw):
+                 predictor_weights=None, enforce_eager: bool = False, codec_eos: int | None = CODEC_EOS, top_k: int = 50,
+                 **kw):
         kw = dict(kw)
+        self.top_k = top_k
         kw.setdefault("max_num_seqs", max(max_streams, 1))
         tkw = dict(kw, enforce_eager=enforce_eager)
         if talker_weights is not None:
@@ -72,7 +74,10 @@ class FrameEngine:
         self.rng = torch.zeros(1, dtype=torch.int64, device=dev)
         self.temps_t = torch.ones(max_streams, dtype=torch.float32, device=dev)
         self.temps_p = torch.ones(max_streams, dtype=torch.float32, device=dev)
-        self.greedy = torch.ones(max_streams, dtype=torch.uint8, device=dev)
+        # greedy flag per row and per model: a request may sample the talker and take the predictor's arg-max or
+        # the reverse (SamplingParams.do_sample of the two requests the reference sends, P/interface.py:1195-1196)
+        self.greedy_t = torch.ones(max_streams, dtype=torch.uint8, device=dev)
+        self.greedy_p = torch.ones(max_streams, dtype=torch.uint8, device=dev)
         self.ptab_ptrs = torch.tensor([t.data_ptr() for t in self.pr.tables], dtype=torch.int64, device=dev)
         self.rows: list[Stream | None] = [None] * max_streams
         self.streams: dict[str, Stream] = {}
@@ -83,7 +88,6 @@ class FrameEngine:
         self._pred_meta_bs = None
         self._next_sid = 0
         self.stream = self.tr.stream
-        self.top_k = 50
         # Run every kernel of the frame once, eagerly, with all rows inactive (context 0, slot -1:
         # nothing is stored, nothing advances) so that no code object is first loaded under capture.
         with self.tr.on_stream():
@@ -106,6 +110,10 @@ class FrameEngine:
         self._next_sid += 1
         tsp = talker_sampling or SamplingParams(temperature=1.0, max_tokens=1)
         psp = predictor_sampling or SamplingParams(temperature=0.9, max_tokens=17)
+        for sp in (tsp, psp):
+            if sp.do_sample and sp.top_k != self.top_k:
+                raise ValueError(f"top_k={sp.top_k}: the frame graphs are captured for top_k={self.top_k} (the reference's "
+                                 f"sampler default, P/layers/sampler.py:15); build the engine with another top_k to change it")
         L = prompt_embeds.shape[-2]
         total = L + max_frames + 1
         assert total <= self.tr.config.max_model_len, "prompt + frames exceed max_model_len (1024)"
@@ -128,7 +136,8 @@ class FrameEngine:
             self.ctx_limit[row] = total - 1                # the talker step that closes frame max_frames - 1
             self.temps_t[row] = tsp.temperature
             self.temps_p[row] = psp.temperature
-            self.greedy[row] = 0 if (tsp.do_sample or psp.do_sample) else 1
+            self.greedy_t[row] = 0 if tsp.do_sample else 1
+            self.greedy_p[row] = 0 if psp.do_sample else 1
             # talker decode metadata for the token that WILL be fed next: prepare_decode_talker semantics
             st, mb = self.tr.dstage, self.tr.max_blocks_per_seq
             n = len(seq)                                   # L + 1
@@ -206,7 +215,7 @@ class FrameEngine:
         H = self.H
         hip.check(lib.qtts_predictor_input(hip.ptr(self.cur_hidden), hip.ptr(tr.codec_embedding), hip.ptr(self.cur_token),
                                            hip.ptr(pr.e_buf), bs, H, tr.vocab, s()), "predictor_input")
-        pr._greedy_bytes, pr._top_k = self.greedy, self.top_k
+        pr._greedy_bytes, pr._top_k = self.greedy_p, self.top_k
         pr._burst_temps, pr._burst_rng = self.temps_p, self.rng
         pr._burst_body(bs)
         hip.check(lib.qtts_frame_glue(hip.ptr(tr.codec_embedding), hip.ptr(self.ptab_ptrs), hip.ptr(self.cur_token),
@@ -224,7 +233,7 @@ class FrameEngine:
         tr.decoder.forward_logits(self.next_x[:bs], st.d("positions")[:bs], st.d("slots")[:bs], st.d("ctx")[:bs],
                                   st.d("tables")[:bs * mb].view(bs, mb), max_context, tr.codec_head, tr.vocab,
                                   hidden_out=self.cur_hidden[:bs], logits_out=tr.logits[:bs])
-        hip.check(lib.qtts_pick_token(hip.ptr(tr.logits), tr.vocab, hip.ptr(self.temps_t), hip.ptr(self.greedy),
+        hip.check(lib.qtts_pick_token(hip.ptr(tr.logits), tr.vocab, hip.ptr(self.temps_t), hip.ptr(self.greedy_t),
                                       self.top_k, tr.rng_seed, 32, hip.ptr(self.rng), hip.ptr(self.cur_token), 1, bs,
                                       tr.vocab, s()), "pick_token")
 

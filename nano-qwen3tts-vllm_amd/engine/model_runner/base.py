@@ -83,7 +83,10 @@ class ModelRunner:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.full_config = Qwen3TTSConfig.from_model_dir(config.model)
         self.max_blocks_per_seq = (config.max_model_len + self.block_size - 1) // self.block_size
-        self.rng_seed = int(os.environ.get("QTTS_SEED", "0"))
+        # QTTS_SEED pins the sampler's counter RNG (reproducible runs); unset, every process draws its own stream, as
+        # the reference's unseeded torch generator does
+        seed = os.environ.get("QTTS_SEED")
+        self.rng_seed = int(seed) if seed is not None else (int.from_bytes(os.urandom(8), "little") >> 1)
         self.rng_offset = 0
         # All launches go to one side stream: hipGraph capture is not allowed on the legacy
         # default stream, and a private stream keeps replays ordered with the staging copies.

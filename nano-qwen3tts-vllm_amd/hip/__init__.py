@@ -64,6 +64,7 @@ _SIGS = {
     "qtts_model_set_layer_fp8": (_i, [_p, _i] + [_p] * 12),
     "qtts_model_set_layer": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "qtts_model_set_final_norm": (_i, [_p, _p]),
+    "qtts_model_set_layer_events": (_i, [_p, _i, _p, _p]),
     "qtts_model_set_rope": (_i, [_p, _p, _p, _i]),
     "qtts_model_set_kv_cache": (_i, [_p, _p, _i]),
     "qtts_model_workspace_bytes": (_sz, [_p, _i, _i]),

@@ -14,10 +14,12 @@ third-party packages; `create_voice_clone_prompt` keeps its signature and raises
 from __future__ import annotations
 
 import asyncio
+import functools
 import json
 import logging
 import os
 import uuid
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
@@ -104,6 +106,7 @@ class Qwen3TTSInterface:
         # talker and the predictor ("fused", the default)
         self._async_engine = os.environ.get("QTTS_ASYNC_ENGINE", "fused")
         self._fused_task: asyncio.Task | None = None
+        self._fused_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="qtts-frame-engine")
         self._fused_pending: list = []
         self._fused_cancelled: list = []
         self._fused_wake: asyncio.Event | None = None
@@ -200,6 +203,13 @@ class Qwen3TTSInterface:
         from .engine.frame_engine import NoCapacity
         fe = self._frame_engine
         budget: dict[str, int] = {}
+        # The engine's blocking calls (a frame: about 3 ms until the codes are on the host; an admission: the prompt's
+        # prefill) run on one worker thread, so the event loop keeps serving its other coroutines - an HTTP server's
+        # handlers, the streams' consumers - meanwhile.  Only this coroutine talks to the engine, one call at a time.
+        loop = asyncio.get_running_loop()
+
+        def off_loop(fn, *a, **k):
+            return loop.run_in_executor(self._fused_pool, functools.partial(fn, *a, **k))
         while True:
             for rid in self._fused_cancelled:
                 fe.remove_stream(rid)
@@ -212,7 +222,8 @@ class Qwen3TTSInterface:
                     still_waiting.append(req)
                     continue
                 try:
-                    fe.add_stream(prompt, text_adds, max_frames=n, talker_sampling=tsp, predictor_sampling=psp, sid=rid)
+                    await off_loop(fe.add_stream, prompt, text_adds, max_frames=n, talker_sampling=tsp,
+                                   predictor_sampling=psp, sid=rid)
                     budget[rid] = n
                     continue
                 except NoCapacity as e:
@@ -220,7 +231,7 @@ class Qwen3TTSInterface:
                         still_waiting.append(req)
                         continue
                     reason = e
-                except AssertionError as e:                       # can never fit (prompt + frames > max_model_len)
+                except (AssertionError, ValueError) as e:         # can never be served (too long, unsupported top_k)
                     reason = e
                 logger.warning(f"[fused_loop] request {rid[:8]} rejected: {reason}")
                 q = self._request_queues.get(rid)
@@ -233,7 +244,7 @@ class Qwen3TTSInterface:
                     await self._fused_wake.wait()
                 continue
             active = list(fe.streams)
-            res = fe.step()
+            res = await off_loop(fe.step)
             for rid in active:
                 q = self._request_queues.get(rid)
                 frame = res.get(rid)
@@ -245,7 +256,6 @@ class Qwen3TTSInterface:
                     budget.pop(rid, None)
                     if q is not None:
                         q.put_nowait(None)
-            await asyncio.sleep(0)                                # consumers and new requests run between frames
 
     async def _generate_async_fused(self, inputs_embeds, trailing_text_hiddens, tts_pad_embed, request_id):
         fe = self._frame_engine

@@ -1,0 +1,304 @@
+"""Data-parallel serving: N independent engine replicas, one process per GPU, and a router that
+places every new stream on the least-loaded replica.
+
+A stream's frame loop is sequential and the whole model fits one GPU, so the only way eight GPUs
+help is by running different streams — there is no collective, no RCCL and no traffic between the
+replicas; the router lives on the host.  The reference has no counterpart: it spawns its two engine
+processes for ONE GPU (P/workers/client_bridge.py:182-271, `mp.get_context("spawn")`, one command and
+one result channel per process — the pattern kept here) and points at `uvicorn --workers N` for more
+(examples/server.py:6).
+
+    pool = ReplicaPool(n_replicas=8, factory="nano_qwen3tts_vllm.replicas:frame_engine_factory",
+                       factory_kwargs=dict(model_dir=..., max_streams=8))
+    for frame in pool.generate(prompt_embeds, text_adds, max_frames=125): ...
+    async for frame in pool.generate_async(...): ...
+    pool.close()
+
+A replica process pins itself to its GPU (`HIP_VISIBLE_DEVICES=<index>`, set before anything touches
+a GPU, so device 0 inside the process is that GPU — which also keeps code that hard-wires device 0
+working), builds its engine with `factory(**factory_kwargs)` and serves the engine protocol of
+`engine.frame_engine.FrameEngine`: `add_stream / step / remove_stream / streams`.
+"""
+from __future__ import annotations
+
+import asyncio
+import importlib
+import multiprocessing as mp
+import os
+import queue
+import threading
+import traceback
+import uuid
+
+import numpy as np
+
+_CMD_ADD, _CMD_CANCEL, _CMD_SHUTDOWN = "add", "cancel", "shutdown"
+_END = None                      # a stream's last message: (rid, None, reason)
+
+
+def frame_engine_factory(model_dir: str, max_streams: int = 8, capture: bool = True, **kw):
+    """The production engine of a replica: a FrameEngine on the process's (only visible) GPU with every frame graph
+    captured before the first request."""
+    from .engine.frame_engine import FrameEngine
+    fe = FrameEngine(model_dir, max_streams=max_streams, **kw)
+    if capture:
+        fe.capture_all()
+    return fe
+
+
+def _resolve(spec: str):
+    mod, _, name = spec.partition(":")
+    return getattr(importlib.import_module(mod), name)
+
+
+def _to_tensor(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def replica_main(index: int, device_index: int | None, factory: str, factory_kwargs: dict, cmd_q, res_q):
+    """Body of one replica process: pin the GPU, build the engine, then loop — take commands (blocking only while
+    idle), admit what fits, run one frame for every active stream, send the frames."""
+    if device_index is not None:
+        os.environ["HIP_VISIBLE_DEVICES"] = str(device_index)      # before any GPU call of this process
+    try:
+        engine = _resolve(factory)(**factory_kwargs)
+    except Exception:
+        res_q.put(("__replica__", index, "failed", traceback.format_exc()))
+        return
+    res_q.put(("__replica__", index, "ready", None))
+    from .sampling_params import SamplingParams
+    waiting: list = []
+    running = True
+    while running or engine.streams:
+        # commands: block only when there is nothing to run
+        block = not engine.streams and not waiting
+        while True:
+            try:
+                cmd = cmd_q.get(block=block, timeout=0.5 if block else None)
+            except queue.Empty:
+                break
+            block = False
+            if cmd[0] == _CMD_SHUTDOWN:
+                running = False
+                waiting.clear()
+                for sid in list(engine.streams):
+                    engine.remove_stream(sid)
+            elif cmd[0] == _CMD_CANCEL:
+                waiting[:] = [w for w in waiting if w[1] != cmd[1]]
+                engine.remove_stream(cmd[1])
+            elif cmd[0] == _CMD_ADD and running:
+                waiting.append(cmd)
+        still = []
+        for cmd in waiting:
+            _, rid, prompt, text_adds, max_frames, tsp, psp = cmd
+            try:
+                engine.add_stream(_to_tensor(prompt), _to_tensor(text_adds), max_frames=max_frames,
+                                  talker_sampling=SamplingParams(**tsp), predictor_sampling=SamplingParams(**psp), sid=rid)
+            except Exception as e:
+                if type(e).__name__ == "NoCapacity" and engine.streams:
+                    still.append(cmd)                  # a row / KV blocks come back when a running stream ends
+                else:
+                    res_q.put((rid, _END, f"rejected: {e}"))
+        waiting[:] = still
+        if not engine.streams:
+            continue
+        active = list(engine.streams)
+        try:
+            frames = engine.step()
+        except Exception:
+            err = traceback.format_exc()
+            for rid in active:
+                res_q.put((rid, _END, "engine error: " + err))
+                engine.remove_stream(rid)
+            continue
+        for rid in active:
+            if rid in frames:
+                res_q.put((rid, list(frames[rid]), None))
+            if rid not in engine.streams:              # codec EOS or the stream's frame budget
+                res_q.put((rid, _END, "finished"))
+    if hasattr(engine, "exit"):
+        engine.exit()
+    res_q.put(("__replica__", index, "stopped", None))
+
+
+class ReplicaPool:
+    """N replica processes and the host-side router: a new stream goes to the replica with the fewest streams in
+    flight (lowest index on ties) and stays there; a replica at `max_streams_per_replica` takes no more until one of
+    its streams ends, further requests wait in the router (first come, first served)."""
+
+    def __init__(self, n_replicas: int, factory: str, factory_kwargs: dict | None = None, devices: list | None = None,
+                 max_streams_per_replica: int = 8, start_timeout: float = 600.0):
+        assert n_replicas >= 1
+        self.n = n_replicas
+        self.cap = max_streams_per_replica
+        self._ctx = mp.get_context("spawn")               # a fresh interpreter per replica: no inherited GPU state
+        self._res_q = self._ctx.Queue()
+        self._cmd_qs = [self._ctx.Queue() for _ in range(n_replicas)]
+        devices = devices if devices is not None else list(range(n_replicas))
+        assert len(devices) == n_replicas
+        self._procs = [self._ctx.Process(target=replica_main, name=f"qtts-replica-{i}", daemon=True,
+                                         args=(i, devices[i], factory, dict(factory_kwargs or {}), self._cmd_qs[i], self._res_q))
+                       for i in range(n_replicas)]
+        self._lock = threading.Lock()
+        self._load = [0] * n_replicas
+        self._where: dict[str, int] = {}                   # request id -> replica
+        self._sinks: dict[str, "queue.Queue"] = {}       # per request: where its frames go, until the consumer is done
+        self._live: set[str] = set()                       # requests waiting in the router or running on a replica
+        self._backlog: list = []
+        self._closed = False
+        self.placements: list[tuple[str, int]] = []        # (request id, replica) in admission order
+        for p in self._procs:
+            p.start()
+        ready = 0
+        while ready < n_replicas:
+            try:
+                tag, idx, state, info = self._res_q.get(timeout=start_timeout)
+            except queue.Empty:
+                self.close()
+                raise RuntimeError("replicas did not come up in time")
+            if tag != "__replica__" or state != "ready":
+                self.close()
+                raise RuntimeError(f"replica {idx} failed to start:\n{info}")
+            ready += 1
+        self._pump = threading.Thread(target=self._pump_results, name="qtts-replica-results", daemon=True)
+        self._pump.start()
+
+    # ---------------------------------------------------------------- routing
+    def _pick(self) -> int | None:
+        best = min(range(self.n), key=lambda i: (self._load[i], i))
+        return best if self._load[best] < self.cap else None
+
+    def _place_locked(self):
+        while self._backlog:
+            i = self._pick()
+            if i is None:
+                return
+            msg = self._backlog.pop(0)
+            rid = msg[1]
+            if rid not in self._live:                      # cancelled while waiting
+                continue
+            self._load[i] += 1
+            self._where[rid] = i
+            self.placements.append((rid, i))
+            self._cmd_qs[i].put(msg)
+
+    def submit(self, prompt_embeds, text_adds, max_frames: int, talker_sampling=None, predictor_sampling=None,
+               request_id: str | None = None) -> str:
+        """Queue a stream; its frames arrive through `frames(request_id)`.  prompt_embeds [L,H], text_adds fp32 [F,H]
+        (torch tensors or numpy arrays; they travel to the replica as numpy)."""
+        from .sampling_params import SamplingParams
+        if self._closed:
+            raise RuntimeError("the replica pool is closed")
+        rid = request_id or str(uuid.uuid4())
+        tsp = talker_sampling or SamplingParams(temperature=1.0, max_tokens=1)
+        psp = predictor_sampling or SamplingParams(temperature=0.9, max_tokens=17)
+        as_np = lambda t: np.asarray(t.detach().float().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
+        msg = (_CMD_ADD, rid, as_np(prompt_embeds), as_np(text_adds), int(max_frames), _sp_dict(tsp), _sp_dict(psp))
+        with self._lock:
+            self._sinks[rid] = queue.Queue()
+            self._live.add(rid)
+            self._backlog.append(msg)
+            self._place_locked()
+        return rid
+
+    def cancel(self, request_id: str):
+        with self._lock:
+            sink = self._sinks.get(request_id)
+            was_live = request_id in self._live
+            self._live.discard(request_id)
+            i = self._where.pop(request_id, None)
+            if i is not None:
+                self._load[i] -= 1
+                self._cmd_qs[i].put((_CMD_CANCEL, request_id))
+            self._place_locked()
+        if sink is not None and was_live:
+            sink.put((_END, "cancelled"))
+
+    def _pump_results(self):
+        while True:
+            try:
+                item = self._res_q.get(timeout=0.5)
+            except queue.Empty:
+                if self._closed:
+                    return
+                continue
+            if item[0] == "__replica__":
+                continue
+            rid, frame, reason = item
+            with self._lock:
+                if rid not in self._live:                  # cancelled: the replica's late messages are dropped
+                    continue
+                sink = self._sinks.get(rid)
+                if frame is _END:
+                    self._live.discard(rid)
+                    i = self._where.pop(rid, None)
+                    if i is not None:
+                        self._load[i] -= 1
+                    self._place_locked()
+            if sink is not None:
+                sink.put((frame, reason))
+
+    # ---------------------------------------------------------------- consumers
+    def frames(self, request_id: str, timeout: float | None = 120.0):
+        """Generator over the stream's 16-id frames, in order; ends when the replica finishes the stream."""
+        sink = self._sinks.get(request_id)
+        if sink is None:
+            return
+        try:
+            while True:
+                frame, reason = sink.get(timeout=timeout)
+                if frame is _END:
+                    if reason and reason not in ("finished", "cancelled"):
+                        raise RuntimeError(f"stream {request_id}: {reason}")
+                    return
+                yield frame
+        finally:
+            if request_id in self._live:
+                self.cancel(request_id)
+            self._sinks.pop(request_id, None)
+
+    def generate(self, prompt_embeds, text_adds, max_frames: int, **kw):
+        return self.frames(self.submit(prompt_embeds, text_adds, max_frames, **kw))
+
+    async def generate_async(self, prompt_embeds, text_adds, max_frames: int, **kw):
+        """Async generator of frames: the blocking queue reads run in the default executor, so the event loop stays
+        free for other requests."""
+        rid = self.submit(prompt_embeds, text_adds, max_frames, **kw)
+        sink = self._sinks[rid]
+        loop = asyncio.get_running_loop()
+        try:
+            while True:
+                frame, reason = await loop.run_in_executor(None, sink.get)
+                if frame is _END:
+                    if reason and reason not in ("finished", "cancelled"):
+                        raise RuntimeError(f"stream {rid}: {reason}")
+                    return
+                yield frame
+        finally:
+            if rid in self._live:
+                self.cancel(rid)
+            self._sinks.pop(rid, None)
+
+    def load(self) -> list[int]:
+        with self._lock:
+            return list(self._load)
+
+    def close(self, timeout: float = 10.0):
+        if self._closed:
+            return
+        self._closed = True
+        for q_ in self._cmd_qs:
+            try:
+                q_.put((_CMD_SHUTDOWN,))
+            except Exception:
+                pass
+        for p in self._procs:
+            p.join(timeout=timeout)
+            if p.is_alive():
+                p.terminate()                              # the exact processes this pool started
+
+
+def _sp_dict(sp) -> dict:
+    return dict(temperature=sp.temperature, max_tokens=sp.max_tokens, ignore_eos=sp.ignore_eos,
+                do_sample=sp.do_sample, top_k=sp.top_k, top_p=sp.top_p)

@@ -1,0 +1,56 @@
+"""A deterministic stand-in for FrameEngine (same protocol: add_stream / step / remove_stream / streams) that the
+replica-pool tests run in CPU processes.  A stream's frame f is 16 ids derived from its prompt's checksum, the frame
+index and the replica's tag, so a test can tell which replica served a stream and that frames arrive in order."""
+import os
+import time
+
+
+class NoCapacity(RuntimeError):
+    pass
+
+
+class _S:
+    def __init__(self, key, max_frames):
+        self.key, self.max_frames, self.n = key, max_frames, 0
+
+
+class FakeEngine:
+    def __init__(self, tag=0, max_streams=2, step_seconds=0.002, fail_on=None):
+        self.tag, self.max_streams, self.step_seconds, self.fail_on = tag, max_streams, step_seconds, fail_on
+        self.streams = {}
+        self.visible = os.environ.get("HIP_VISIBLE_DEVICES")
+
+    def add_stream(self, prompt_embeds, text_adds, max_frames, talker_sampling=None, predictor_sampling=None, sid=None):
+        if len(self.streams) >= self.max_streams:
+            raise NoCapacity("all stream rows are taken")
+        if prompt_embeds.shape[0] + max_frames > 1024:
+            raise AssertionError("prompt + frames exceed max_model_len (1024)")
+        self.streams[sid] = _S(int(prompt_embeds.float().sum().item()) % 1000, max_frames)
+        return sid
+
+    def remove_stream(self, sid):
+        self.streams.pop(sid, None)
+
+    def step(self):
+        time.sleep(self.step_seconds)
+        out = {}
+        for sid, s in list(self.streams.items()):
+            if self.fail_on is not None and s.key == self.fail_on:
+                raise RuntimeError("injected engine failure")
+            dev = int(self.visible) if self.visible not in (None, "") else -1
+            out[sid] = [s.key, s.n, dev, self.tag] + [0] * 12
+            s.n += 1
+            if s.n >= s.max_frames:
+                del self.streams[sid]
+        return out
+
+    def exit(self):
+        pass
+
+
+def make(**kw):
+    return FakeEngine(**kw)
+
+
+def broken(**kw):
+    raise RuntimeError("no engine today")

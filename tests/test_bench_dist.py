@@ -61,3 +61,18 @@ def test_single_process_defaults(monkeypatch):
     cfg = __import__("nano_qwen3tts_vllm.utils.synthetic", fromlist=["x"]).make_config("1.7B")
     b = bench.algorithmic_bytes_per_frame(cfg, 8, 300)
     assert 5.4e9 < b < 5.8e9                         # 2.83 GB talker + 15 x 0.166 GB predictor + KV rows
+
+
+def test_gpus_flag_starts_its_own_ranks_and_reports_a_failed_one():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* exported per child).  There is no GPU here, so every rank fails at its first GPU call: the launcher must
+    stop the others and exit non-zero, naming the rank - it must not hang or report success."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        env["HIP_VISIBLE_DEVICES"] = ""            # on a GPU box: hide the devices, same outcome
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "rank" in r.stderr and "exited with" in r.stderr
+    assert r.stdout.strip() == ""                  # no JSON line from a failed job

@@ -190,3 +190,68 @@ def test_full_size_batch_invariance_and_graph_equals_eager(tmp_path):
     assert batch.shape == (B, NF, 16)
     assert torch.equal(batch, run(range(B), True)), "graph replay differs from eager launches"
     assert torch.equal(batch[3:4], run([3], False)), "a stream's ids depend on its batch"
+
+
+def test_a_stream_pushed_past_its_frame_budget_cannot_touch_another_streams_kv(tmp_path):
+    """Stream B holds physical KV block 0; stream A (250-token prompt, 4 frames: one KV block reserved, the rest of its
+    block-table row zero) is then driven far past its budget through the engine's launch internals.  The device-side
+    metadata advance freezes A at the context its block covers, so A never follows a table entry that is not its own
+    and B's ids equal a run of B alone.  The public calls refuse to go past the budget in the first place."""
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    cfg, sd, tw, pw = golden_weights("tiny", 11)
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(23)
+    H = cfg["talker_config"]["hidden_size"]
+    pb, pa = torch.randn(12, H, generator=gen) * 0.5, torch.randn(250, H, generator=gen) * 0.5
+    tb, ta = torch.randn(20, H, generator=gen) * 0.3, torch.randn(4, H, generator=gen) * 0.3
+    kw = dict(max_streams=2, max_text_frames=24, talker_weights=tw, predictor_weights=pw, num_kvcache_blocks=4,
+              max_num_batched_tokens=1024, codec_eos=None)
+    solo = FrameEngine(str(tmp_path), **kw)
+    solo.add_stream(pb, tb, max_frames=16, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+    want = solo.run_frames(16)[:, 0].tolist()
+    solo.exit()
+
+    fe = FrameEngine(str(tmp_path), **kw)
+    b = fe.add_stream(pb, tb, max_frames=16, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+    a = fe.add_stream(pa, ta, max_frames=4, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+    assert fe.streams[b].seq.block_table == [0] and len(fe.streams[a].seq.block_table) == 1
+    with pytest.raises(ValueError, match="max_frames"):
+        fe.run_frames(5)                                   # more than A has left
+    got = []
+    with fe.tr.on_stream():                                # the launches themselves, 16 frames, no budget check
+        fe._setup_predictor_meta(2)
+        for f in range(16):
+            fe._launch_codes(2)
+            got.append(fe.codes[0].tolist())
+            fe._launch_talker(2, 384)
+        fe.tr.stream.synchronize()
+    assert got == want
+    st = fe.tr.dstage
+    assert int(st.d("ctx")[1]) == 250 + 4                  # A stopped where its reserved block ends being covered
+    fe.exit()
+
+
+def test_step_finishes_a_stream_at_its_frame_budget(tmp_path):
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    cfg, sd, tw, pw = golden_weights("tiny", 11)
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(4)
+    H = cfg["talker_config"]["hidden_size"]
+    fe = FrameEngine(str(tmp_path), max_streams=2, max_text_frames=8, talker_weights=tw, predictor_weights=pw,
+                     num_kvcache_blocks=4, max_num_batched_tokens=1024, codec_eos=None)
+    free0 = len(fe.talker.scheduler.block_manager.free_block_ids)
+    a = fe.add_stream(torch.randn(6, H, generator=gen) * 0.5, torch.zeros(1, H), max_frames=3, talker_sampling=greedy(1),
+                      predictor_sampling=greedy(17))
+    b = fe.add_stream(torch.randn(9, H, generator=gen) * 0.5, torch.zeros(1, H), max_frames=5, talker_sampling=greedy(1),
+                      predictor_sampling=greedy(17))
+    seen = {a: 0, b: 0}
+    for _ in range(5):
+        for sid in fe.step():
+            seen[sid] += 1
+    assert seen == {a: 3, b: 5} and not fe.streams and fe.step() == {}
+    assert len(fe.talker.scheduler.block_manager.free_block_ids) == free0
+    with pytest.raises(ValueError, match="top_k"):
+        from nano_qwen3tts_vllm.sampling_params import SamplingParams
+        fe.add_stream(torch.zeros(4, H), torch.zeros(1, H), max_frames=2,
+                      talker_sampling=SamplingParams(temperature=1.0, max_tokens=1, do_sample=True, top_k=20))
+    fe.exit()

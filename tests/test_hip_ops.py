@@ -701,3 +701,36 @@ def test_decode_attention_with_a_context_beyond_the_launch(hip):
         assert bool(torch.isfinite(out.float()).all())
     part = ((B * Hq * ((maxc + 127) // 128) * 130 * 4 + 255) // 256) * 256
     assert int(ws[part:part + B * Hkv * 4].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,I,K", [(8, 1024, 2048), (20, 512, 256), (20, 1024, 2048), (3, 512, 3072)])
+def test_swiglu_launches_with_few_tiles_stay_inside_their_output(hip, M, I, K):
+    """Narrow GEMMs with a long K share a 16-row weight tile between two workgroups; that form exists for the plain
+    bias / residual epilogue of a single row tile only.  SwiGLU launches whose size would qualify (few tiles, a large
+    slice per workgroup), with one and with two row tiles, must take the ordinary path: I outputs per row (not 2 I),
+    nothing written past the rows' end (the output sits in the middle of a larger buffer of sentinels), oracle
+    arithmetic.  An out-of-bounds store of exactly this kind aborted a test run during development."""
+    g = torch.Generator().manual_seed(M + I + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    wg = (torch.randn(I, K, generator=g) * 0.05).bfloat16()
+    wu = (torch.randn(I, K, generator=g) * 0.05).bfloat16()
+    want = O.silu_mul(torch.nn.functional.linear(x, wg), torch.nn.functional.linear(x, wu))
+    wp = hip.pack_gate_up(wg.to(DEV), wu.to(DEV))
+    buf = torch.full((M + 8, I), 777.0, dtype=torch.bfloat16, device=DEV)
+    out = buf[4:4 + M]
+    hip.linear_swiglu(x.to(DEV), wp, I, out=out)
+    torch.cuda.synchronize()
+    assert bool((buf[:4] == 777.0).all()) and bool((buf[4 + M:] == 777.0).all())
+    got = out.float().cpu()
+    rel = (got - want.float()).abs() / (want.float().abs() + 1e-3)
+    assert float((rel > 2.0 ** -6).float().mean()) < 1e-3 and float(rel.max()) < 0.1
+    # the same rows through down_proj's form of the activation (silu(gate) * up applied on the way in)
+    gu = torch.cat([torch.nn.functional.linear(x, wg), torch.nn.functional.linear(x, wu)], 1).to(DEV)
+    wd = (torch.randn(256, I, generator=g) * 0.05).bfloat16()
+    buf2 = torch.full((M + 8, 256), 777.0, dtype=torch.bfloat16, device=DEV)
+    if I % 256 == 0:
+        hip.linear_fused(gu, hip.pack_weight(wd.to(DEV)), 256, swiglu_input=True, out=buf2[4:4 + M])
+        torch.cuda.synchronize()
+        assert bool((buf2[:4] == 777.0).all()) and bool((buf2[4 + M:] == 777.0).all())
+        wantd = torch.nn.functional.linear(want, wd).float()
+        assert torch.allclose(buf2[4:4 + M].float().cpu(), wantd, atol=2e-2, rtol=2e-2)

@@ -1,0 +1,88 @@
+"""CPU, real processes: the data-parallel replica pool (nano_qwen3tts_vllm/replicas.py) with stand-in engines —
+least-loaded placement, per-replica GPU pinning, ordered frames, waiting when every replica is full, cancellation,
+engine failures, start-up failures."""
+import asyncio
+
+import pytest
+import torch
+
+from nano_qwen3tts_vllm.replicas import ReplicaPool
+
+FACTORY = "fake_replica_engine:make"
+
+
+def _prompt(key, L=4):
+    p = torch.zeros(L, 8)
+    p[0, 0] = key
+    return p
+
+
+@pytest.fixture()
+def pool():
+    p = ReplicaPool(2, FACTORY, dict(max_streams=2, step_seconds=0.005), max_streams_per_replica=2, start_timeout=120)
+    yield p
+    p.close()
+
+
+def test_least_loaded_placement_and_ordered_frames(pool):
+    text = torch.zeros(3, 8)
+    rids = [pool.submit(_prompt(10 + i), text, max_frames=20 + 5 * i, request_id=f"r{i}") for i in range(4)]
+    # four streams over two replicas with room for two each: alternating, lowest index first
+    assert pool.placements == [("r0", 0), ("r1", 1), ("r2", 0), ("r3", 1)]
+    assert pool.load() == [2, 2]
+    for i, rid in enumerate(rids):
+        frames = list(pool.frames(rid))
+        assert len(frames) == 20 + 5 * i and all(len(f) == 16 for f in frames)
+        assert [f[1] for f in frames] == list(range(len(frames)))            # in order
+        assert all(f[0] == 10 + i for f in frames)
+        # the replica it was placed on served it, pinned to its own GPU index
+        assert {f[2] for f in frames} == {i % 2}
+    assert pool.load() == [0, 0]
+
+
+def test_requests_wait_for_a_free_replica_and_cancel(pool):
+    text = torch.zeros(2, 8)
+    long_ids = [pool.submit(_prompt(i), text, max_frames=400, request_id=f"long{i}") for i in range(4)]
+    waiting = pool.submit(_prompt(77), text, max_frames=3, request_id="late")
+    assert pool.load() == [2, 2] and ("late", 0) not in pool.placements and ("late", 1) not in pool.placements
+    it = pool.frames("long1")
+    assert next(it)[0] == 1
+    it.close()                                        # the consumer goes away: the stream is cancelled on its replica
+    got = list(pool.frames(waiting))                  # ... and the waiting request takes the freed place
+    assert [f[1] for f in got] == [0, 1, 2]
+    assert dict(pool.placements)["late"] == 1
+    for rid in long_ids:
+        pool.cancel(rid)
+    assert pool.load() == [0, 0]
+
+
+def test_generate_async_streams_concurrently(pool):
+    text = torch.zeros(2, 8)
+
+    async def run():
+        async def one(i):
+            return [f async for f in pool.generate_async(_prompt(30 + i), text, max_frames=6, request_id=f"a{i}")]
+        return await asyncio.gather(*(one(i) for i in range(4)))
+
+    res = asyncio.run(run())
+    for i, frames in enumerate(res):
+        assert [f[:2] for f in frames] == [[30 + i, n] for n in range(6)]
+    assert sorted(r for _, r in pool.placements) == [0, 0, 1, 1]
+
+
+def test_rejected_and_failing_streams_end_with_an_error():
+    pool = ReplicaPool(1, FACTORY, dict(max_streams=2, fail_on=5), devices=[None], max_streams_per_replica=2, start_timeout=120)
+    try:
+        with pytest.raises(RuntimeError, match="rejected"):
+            list(pool.generate(_prompt(1, L=1000), torch.zeros(1, 8), max_frames=100))
+        with pytest.raises(RuntimeError, match="injected engine failure"):
+            list(pool.generate(_prompt(5), torch.zeros(1, 8), max_frames=4))
+        ok = list(pool.generate(_prompt(6), torch.zeros(1, 8), max_frames=4))          # the replica keeps serving
+        assert len(ok) == 4 and ok[0][2] == -1                                         # devices=[None]: no pinning
+    finally:
+        pool.close()
+
+
+def test_start_up_failure_is_reported():
+    with pytest.raises(RuntimeError, match="no engine today"):
+        ReplicaPool(1, "fake_replica_engine:broken", {}, start_timeout=120)

@@ -1,0 +1,31 @@
+"""Makes the measurement scripts use the -DQTTS_TUNING build of the library (csrc/libqtts_hip_tuning.so: dispatch
+thresholds as settable process-wide variables, in-kernel timestamps, the grid-barrier probe, the resident burst
+kernel).  Import this module before nano_qwen3tts_vllm.hip; the shipped library has none of these entry points.
+
+    python nano-qwen3tts-vllm_amd/csrc/build.py --tuning      # once, in the build container
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "nano-qwen3tts-vllm_amd", "csrc", "libqtts_hip_tuning.so")
+if not os.path.exists(LIB):
+    raise SystemExit(f"{LIB} is missing: build it with `python nano-qwen3tts-vllm_amd/csrc/build.py --tuning`")
+os.environ["QTTS_LIB"] = LIB
+sys.path.insert(0, ROOT)
+from nano_qwen3tts_vllm import hip  # noqa: E402
+
+_p, _i = C.c_void_p, C.c_int
+for _name, (_res, _args) in {
+    "qtts_tune_linear": (None, [_i, _i]),
+    "qtts_tune_subtiles": (None, [_i]),
+    "qtts_tune_prompt_attention": (None, [_i]),
+    "qtts_tune_rows": (None, [_i]),
+    "qtts_tune_shared_prologue": (None, [_i]),
+    "qtts_debug_linear": (None, [_i]),
+    "qtts_debug_linear_trace": (None, [_p]),
+    "qtts_debug_grid_barrier": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
+}.items():
+    _fn = getattr(hip.lib, _name)
+    _fn.restype, _fn.argtypes = _res, _args

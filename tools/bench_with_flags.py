@@ -1,5 +1,7 @@
 import os, sys
 sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning  # noqa: F401  (the -DQTTS_TUNING build of the library)
 from nano_qwen3tts_vllm import hip
 hip.lib.qtts_debug_linear(int(os.environ.get("QTTS_LINEAR_DBG", "0")))
 sys.argv = ["bench.py"] + sys.argv[1:]

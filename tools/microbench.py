@@ -10,6 +10,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning  # noqa: F401  (the -DQTTS_TUNING build of the library)
 from nano_qwen3tts_vllm import hip
 
 dev = torch.device("cuda", 0)

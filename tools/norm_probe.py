@@ -1,5 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning  # noqa: F401  (the -DQTTS_TUNING build of the library)
 from nano_qwen3tts_vllm import hip
 sys.path.insert(0, "/root/repo/tools")
 dev = torch.device("cuda")
