@@ -224,7 +224,7 @@ def percentile(xs, q):
     return xs[min(len(xs) - 1, int(round(q * (len(xs) - 1))))] if xs else None
 
 
-def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed):
+def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed, overlap=False):
     """BASELINE.json configs[2] as a serving workload: `streams` requests arrive `gap_s` apart (prompt lengths cycling
     through `lens`), each wants `frames` frames; admission and prefill happen inside the timed region, between two
     frames of the running batch, as a server's loop does.  Returns throughput and latency statistics; the clock is
@@ -246,7 +246,7 @@ def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed):
             L, prompt, text = reqs[nxt]
             try:
                 sid = fe.add_stream(prompt, text, max_frames=frames, talker_sampling=samplers[0], predictor_sampling=samplers[1],
-                                    sid=f"arr-{nxt}")
+                                    sid=f"arr-{nxt}", wait=not overlap)
             except NoCapacity:
                 break                                  # admitted as soon as a running stream ends
             sid_of[sid] = nxt
@@ -276,6 +276,7 @@ def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed):
             "rtf_per_stream_mean": statistics.fmean((last[i] - arrival[i]) / (frames * FRAME_SECONDS) for i in range(streams)),
             "first_chunk_ms_p50": ms(percentile(list(first.values()), 0.5)), "first_chunk_ms_p99": ms(percentile(list(first.values()), 0.99)),
             "inter_chunk_ms_p50": ms(percentile(gaps, 0.5)), "inter_chunk_ms_p99": ms(percentile(gaps, 0.99)),
+            "admission": "prefill on a second stream beside the running frames" if overlap else "prefill between two frames",
             "note": "prefill and admission inside the timed region; first chunk = arrival -> the stream's first 16-code frame on the host"}
 
 
@@ -356,7 +357,9 @@ def main():
     # by rank 0 at N = 1 beside the contract number)
     arrivals = None
     if not args.no_arrivals and world == 1:
-        arrivals = run_arrivals(fe, device, H, B, ARRIVAL_FRAMES, ARRIVAL_GAP_S, lens, (greedy_t, greedy_p), 2000 + rank)
+        overlap = os.environ.get("QTTS_OVERLAP_PREFILL", "0") == "1"
+        run_arrivals(fe, device, H, 2, 3, 0.0, lens, (greedy_t, greedy_p), 1999, overlap)      # (first use of the second stream)
+        arrivals = run_arrivals(fe, device, H, B, ARRIVAL_FRAMES, ARRIVAL_GAP_S, lens, (greedy_t, greedy_p), 2000 + rank, overlap)
         assert not fe.streams
 
     # ---- the contract number: B streams admitted, steady-state frames

@@ -37,9 +37,13 @@ class Stream:
         self.sid, self.row, self.seq, self.n_text, self.max_frames = sid, row, seq, n_text, max_frames
         self.frames: list[list[int]] = []
         self.finished = False
+        self.active = True            # False while the stream's prefill is still running beside the frames
+        self.ready = None             # the event that prefill ends with
 
 
 class FrameEngine:
+    overlapped_admission = True       # add_stream(wait=False) prefills beside the running frames
+
     def __init__(self, model_dir: str, max_streams: int = 8, max_text_frames: int = 1024, talker_weights=None,
                  predictor_weights=None, enforce_eager: bool = False, codec_eos: int | None = CODEC_EOS, top_k: int = 50,
                  **kw):
@@ -79,6 +83,14 @@ class FrameEngine:
         self.greedy_t = torch.ones(max_streams, dtype=torch.uint8, device=dev)
         self.greedy_p = torch.ones(max_streams, dtype=torch.uint8, device=dev)
         self.ptab_ptrs = torch.tensor([t.data_ptr() for t in self.pr.tables], dtype=torch.int64, device=dev)
+        # a prompt prefilled beside the running frames (add_stream(wait=False)) leaves its results here until the
+        # stream is switched on between two frames: the frame graphs rewrite cur_hidden / cur_token of every row
+        self.pend_hidden = torch.zeros(max_streams, H, dtype=torch.bfloat16, device=dev)
+        self.pend_token = torch.zeros(max_streams, dtype=torch.int64, device=dev)
+        self._pre_temp = torch.ones(1, dtype=torch.float32, device=dev)
+        self.pre_stream = torch.cuda.Stream(device=dev)          # prefill beside the frames
+        self._prefill_running: Stream | None = None               # at most one detached prefill in flight
+        self._prefill_waiting: list = []                          # (stream, sampling) admitted, prefill not started yet
         self.rows: list[Stream | None] = [None] * max_streams
         self.streams: dict[str, Stream] = {}
         self.graphs: dict[tuple, hip.Graph] = {}            # talker part, per (batch bucket, context bucket)
@@ -100,9 +112,14 @@ class FrameEngine:
     # ---------------------------------------------------------------- admission
     def add_stream(self, prompt_embeds: torch.Tensor, text_adds: torch.Tensor, max_frames: int,
                    talker_sampling: SamplingParams | None = None, predictor_sampling: SamplingParams | None = None,
-                   sid: str | None = None) -> str:
+                   sid: str | None = None, wait: bool = True) -> str:
         """prompt_embeds [L,H]; text_adds fp32 [F,H]: what the API adds to the codec-embedding sum at
-        frame f (trailing text hiddens, then the tts pad embedding; the last row repeats)."""
+        frame f (trailing text hiddens, then the tts pad embedding; the last row repeats).
+        wait=True: the prompt is prefilled before this returns and the stream takes part in the next frame.
+        wait=False (serving loops): the row and the KV blocks are reserved and the call returns; the prefill runs on a
+        second HIP stream BESIDE the frames of the running streams instead of between two of them, and the stream
+        joins the batch at the first frame boundary after it has finished (one prefill at a time, in arrival order).
+        Same launches, same ids either way."""
         row = next((i for i, s in enumerate(self.rows) if s is None), None)
         if row is None:
             raise NoCapacity("all stream rows are taken")
@@ -124,14 +141,16 @@ class FrameEngine:
             raise NoCapacity(f"{need} KV blocks needed, {len(bm.free_block_ids)} free")
         seq.block_table = [bm._take() for _ in range(need)]
         with self.tr.on_stream():
-            toks, hidden = self.tr._run([seq], True)          # prefill (eager path of the runner)
-            seq.append_token(toks[0], None)
+            if wait:
+                toks, hidden = self.tr._run([seq], True)      # prefill (eager path of the runner)
+                seq.append_token(toks[0], None)
             F = min(text_adds.shape[0], self.max_text_frames)
             self.text_add[row, :F].copy_(text_adds[:F].to(self.device, torch.float32), non_blocking=True)
             if F < self.max_text_frames:
                 self.text_add[row, F:] = text_adds[F - 1].to(self.device, torch.float32)
-            self.cur_hidden[row].copy_(hidden[0])
-            self.cur_token[row] = toks[0]
+            if wait:
+                self.cur_hidden[row].copy_(hidden[0])
+                self.cur_token[row] = toks[0]
             self.frame_idx[row] = 0
             self.ctx_limit[row] = total - 1                # the talker step that closes frame max_frames - 1
             self.temps_t[row] = tsp.temperature
@@ -140,19 +159,79 @@ class FrameEngine:
             self.greedy_p[row] = 0 if psp.do_sample else 1
             # talker decode metadata for the token that WILL be fed next: prepare_decode_talker semantics
             st, mb = self.tr.dstage, self.tr.max_blocks_per_seq
-            n = len(seq)                                   # L + 1
+            n = L + 1                                      # len(seq) once the prefill's first code is appended
             st.h("positions")[row] = n - 1                 # advance_decode adds 1 before the first decode
             st.h("ctx")[row] = n - 1
             st.h("slots")[row] = -1
             tab = st.h("tables")[:self.max_streams * mb].view(self.max_streams, mb)
             tab[row].fill_(0)
             tab[row, :need] = torch.tensor(seq.block_table, dtype=torch.int32)
-            self._sync_row_to_device(row)
+            if wait:
+                self._sync_row_to_device(row)
         s = Stream(sid, row, seq, F, max_frames)
-        s.first_token = toks[0]
         self.rows[row] = s
         self.streams[sid] = s
+        if wait:
+            s.first_token = toks[0]
+        else:
+            s.active = False
+            self._prefill_waiting.append((s, tsp))
+            self._pump_prefills()
         return sid
+
+    # ---------------------------------------------------------------- prefill beside the frames
+    def _start_prefill(self, s: Stream, tsp: SamplingParams):
+        tr = self.tr
+        self.pre_stream.wait_stream(torch.cuda.current_stream(self.device))      # the prompt's producer
+        self.pre_stream.wait_stream(tr.stream)                                   # the row's earlier tenant has left
+        with torch.cuda.stream(self.pre_stream):
+            tr.prefill_detached(s.seq, self.pend_hidden[s.row], self.pend_token[s.row:s.row + 1])
+            s.seq.append_token(-1, None)                  # the first code itself stays on the device (pend_token)
+            if tsp.do_sample:
+                self._pre_temp.fill_(tsp.temperature)
+                hip.check(hip.lib.qtts_sample_topk(hip.ptr(tr.pre_logits), tr.vocab, hip.ptr(self._pre_temp), self.top_k,
+                                                   tr.rng_seed, tr.next_rng_offset() + (1 << 40),
+                                                   hip.ptr(self.pend_token[s.row:s.row + 1]), 1, tr.vocab, hip.stream()),
+                          "sample_topk")
+            s.ready = torch.cuda.Event()
+            s.ready.record(self.pre_stream)
+        self._prefill_running = s
+
+    def _pump_prefills(self, block: bool = False):
+        """Switches a stream on once its prefill has finished (between two frames: called by step / run_frames before
+        they launch) and starts the next waiting prefill.  block: wait for the running prefill (nothing else to do)."""
+        while True:
+            s = self._prefill_running
+            if s is not None:
+                if s.sid not in self.streams or self.streams[s.sid] is not s:      # cancelled meanwhile
+                    s.ready.synchronize()
+                    self._prefill_running = None
+                    continue
+                if not (block or s.ready.query()):
+                    return
+                with self.tr.on_stream():
+                    self.tr.stream.wait_event(s.ready)
+                    self.cur_hidden[s.row].copy_(self.pend_hidden[s.row], non_blocking=True)
+                    self.cur_token[s.row:s.row + 1].copy_(self.pend_token[s.row:s.row + 1], non_blocking=True)
+                    self._sync_row_to_device(s.row)
+                s.active = True
+                self._prefill_running = None
+                block = False
+            self._prefill_waiting = [(w, sp) for w, sp in self._prefill_waiting if self.streams.get(w.sid) is w]
+            if not self._prefill_waiting:
+                return
+            nxt, sp = self._prefill_waiting.pop(0)
+            self._start_prefill(nxt, sp)
+
+    def _activate_or_wait(self) -> bool:
+        """Before a frame: admit what is ready; when no stream is active yet but prefills are under way, wait for the
+        first.  Returns whether any stream is active."""
+        self._pump_prefills()
+        while not any(s.active for s in self.streams.values()):
+            if self._prefill_running is None and not self._prefill_waiting:
+                return False
+            self._pump_prefills(block=True)
+        return True
 
     def _sync_row_to_device(self, row):
         st, mb = self.tr.dstage, self.tr.max_blocks_per_seq
@@ -164,6 +243,10 @@ class FrameEngine:
         s = self.streams.pop(sid, None)
         if s is None:
             return
+        if self._prefill_running is s:               # its prefill still writes the KV blocks that are about to be freed
+            s.ready.synchronize()
+            self._prefill_running = None
+        self._prefill_waiting = [(w, sp) for w, sp in self._prefill_waiting if w is not s]
         self.rows[s.row] = None
         st = self.tr.dstage
         with self.tr.on_stream():
@@ -287,6 +370,9 @@ class FrameEngine:
         """Generate n frames for every active stream back to back (no EOS handling: the caller asked
         for exactly n; a stream with fewer than n frames left of its max_frames is an error, its KV blocks were
         reserved for max_frames).  Returns ids [n, bucket, 16] on the host; one synchronisation at the end."""
+        self._pump_prefills(block=True)
+        while self._prefill_running is not None or self._prefill_waiting:
+            self._pump_prefills(block=True)
         for s in self.streams.values():
             if len(s.frames) + n > s.max_frames:
                 raise ValueError(f"stream {s.sid}: {n} more frames exceed its max_frames={s.max_frames} "
@@ -309,7 +395,7 @@ class FrameEngine:
         """One frame for every active stream; streams whose talker id is the codec EOS finish
         without yielding that frame (as P/interface.py:1233-1239); a stream that has produced its max_frames
         finishes with that frame (the explicit length guard the reference lacks)."""
-        if not self.streams:
+        if not self.streams or not self._activate_or_wait():
             return {}
         bs = self._bucket()
         with self.tr.on_stream():
@@ -325,6 +411,8 @@ class FrameEngine:
             codes = self._codes_host[:bs].tolist()
         res = {}
         for s in list(self.streams.values()):
+            if not s.active:
+                continue
             c = codes[s.row]
             if self.codec_eos is not None and c[0] == self.codec_eos:
                 s.finished = True

@@ -160,6 +160,27 @@ class TalkerModeModelRunner(ModelRunner):
         token_ids = self._pick(seqs, S)
         return token_ids, hidden
 
+    # ---- a prompt's prefill next to running decode steps -------------------------------
+    def prefill_detached(self, seq: Sequence, hidden_out: torch.Tensor, token_out: torch.Tensor):
+        """The prefill of `run([seq], True)` for one sequence, enqueued on the CURRENT stream without any host
+        synchronisation and without touching what the decode steps use: it runs through a twin of the decoder (own
+        workspace) and its own logits row, and leaves the last position's post-norm hidden state in hidden_out [H]
+        and the first code in token_out [1] (int64; arg-max — a sampling request draws its first code from
+        `self.pre_logits` by the caller).  One such prefill may be in flight at a time (the metadata staging buffer
+        is reused).  Same launches, same arithmetic as the synchronous path."""
+        if not hasattr(self, "_twin"):
+            self._twin = self.decoder.twin(self.max_rows, self.config.max_model_len)
+            self.pre_logits = torch.zeros(1, self.vocab, dtype=torch.bfloat16, device=self.device)
+        N, S, cu, max_len = self.prepare_prefill([seq])
+        st, mb = self.pstage, self.max_blocks_per_seq
+        self._twin.forward(self.x_buf[:N], st.d("positions")[:N], st.d("slots")[:N], st.d("ctx")[:N],
+                           st.d("tables")[:mb].view(1, mb), max_len, row_seq=st.d("row_seq")[:N], out=self.h_buf[:N])
+        last = self.h_buf[N - 1:N]
+        hidden_out.copy_(last[0], non_blocking=True)
+        hip.linear(last, self.codec_head, self.vocab, out=self.pre_logits)
+        hip.check(hip.lib.qtts_argmax(hip.ptr(self.pre_logits), self.vocab, hip.ptr(token_out), 1, self.vocab,
+                                      hip.stream()), "argmax")
+
     def exit(self):
         self.graphs.clear()
         super().exit()

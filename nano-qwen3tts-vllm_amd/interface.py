@@ -111,6 +111,9 @@ class Qwen3TTSInterface:
         self._fused_cancelled: list = []
         self._fused_wake: asyncio.Event | None = None
         self.max_streams = int(os.environ.get("QTTS_MAX_STREAMS", "8"))
+        # QTTS_OVERLAP_PREFILL=1: a new prompt is prefilled on a second stream beside the running frames
+        # (add_stream(wait=False)): steadier frames for the running streams, a later first frame for the newcomer
+        self._admit_wait = os.environ.get("QTTS_OVERLAP_PREFILL", "0") != "1"
         self.do_sample = True            # the reference always samples (T=1.0 talker, T=0.9 predictor, top-k 50)
         self.max_frames = 1024           # explicit stop: the reference has no length guard (ends only on codec EOS)
         self.ignore_eos = False          # benchmarks with random weights: keep generating through codec id 2150
@@ -223,7 +226,7 @@ class Qwen3TTSInterface:
                     continue
                 try:
                     await off_loop(fe.add_stream, prompt, text_adds, max_frames=n, talker_sampling=tsp,
-                                   predictor_sampling=psp, sid=rid)
+                                   predictor_sampling=psp, sid=rid, wait=self._admit_wait)
                     budget[rid] = n
                     continue
                 except NoCapacity as e:

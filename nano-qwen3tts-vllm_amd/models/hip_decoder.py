@@ -60,6 +60,7 @@ class HipDecoder:
         self.max_rows, self.max_context, self.max_pos = max_rows, max_context, max_pos
         self.num_kv_blocks = num_kv_blocks
         self._keep = []          # device tensors the C side points into
+        self._layer_calls = []   # (entry point name, arguments) per layer, for twins of this stack
 
         def dev(t):
             t = t.to(device=self.device, dtype=torch.bfloat16).contiguous()
@@ -97,12 +98,13 @@ class HipDecoder:
             if fp8:
                 self._keep += [s_qkv, s_o, s_gu, s_d]
                 self.gate_up_scales = getattr(self, "gate_up_scales", []) + [s_gu]
-                hip.check(hip.lib.qtts_model_set_layer_fp8(h, i, P(norms[0]), P(wqkv_p), P(s_qkv), P(norms[1]), P(norms[2]),
-                                                           P(wo_p), P(s_o), P(norms[3]), P(wgu_p), P(s_gu), P(wd_p), P(s_d)),
-                          "model_set_layer_fp8")
+                call = ("qtts_model_set_layer_fp8", (i, P(norms[0]), P(wqkv_p), P(s_qkv), P(norms[1]), P(norms[2]), P(wo_p), P(s_o),
+                                                     P(norms[3]), P(wgu_p), P(s_gu), P(wd_p), P(s_d)))
             else:
-                hip.check(hip.lib.qtts_model_set_layer(h, i, P(norms[0]), P(wqkv_p), P(norms[1]), P(norms[2]), P(wo_p),
-                                                       P(norms[3]), P(wgu_p), P(wd_p)), "model_set_layer")
+                call = ("qtts_model_set_layer", (i, P(norms[0]), P(wqkv_p), P(norms[1]), P(norms[2]), P(wo_p), P(norms[3]),
+                                                 P(wgu_p), P(wd_p)))
+            hip.check(getattr(hip.lib, call[0])(h, *call[1]), call[0])
+            self._layer_calls.append(call)
         self.final_norm = dev(weights[prefix + "norm.weight"])
         hip.check(hip.lib.qtts_model_set_final_norm(h, hip.ptr(self.final_norm)), "set_final_norm")
         cos, sin = rope_tables(s.head_dim, s.rope_theta, max_pos)
@@ -116,6 +118,31 @@ class HipDecoder:
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         hip.check(hip.lib.qtts_model_set_workspace(h, hip.ptr(self.workspace), nbytes, max_rows, max_context),
                   "set_workspace")
+
+    def twin(self, max_rows: int, max_context: int | None = None) -> "HipDecoder":
+        """A second handle on the same weights, RoPE tables and KV cache with a workspace of its own: forwards through
+        the twin may run on another HIP stream at the same time as forwards through this stack (their activations never
+        share scratch; the KV blocks they touch must be different sequences')."""
+        t = object.__new__(HipDecoder)
+        t.shape, t.device, t.weight_dtype = self.shape, self.device, self.weight_dtype
+        t.max_rows, t.max_context, t.max_pos = max_rows, max_context or self.max_context, self.max_pos
+        t.num_kv_blocks, t.kv_cache, t.final_norm, t.cos, t.sin = self.num_kv_blocks, self.kv_cache, self.final_norm, self.cos, self.sin
+        t._keep, t._layer_calls, t._parent = [], self._layer_calls, self        # the parent owns the tensors
+        s = self.shape
+        h = hip.lib.qtts_model_create(s.hidden_size, s.num_layers, s.num_heads, s.num_kv_heads, s.head_dim,
+                                      s.intermediate_size, s.rms_eps)
+        if not h:
+            raise hip.QttsError("model_create: " + hip.lib.qtts_last_error().decode())
+        t._h = h
+        for name, args in self._layer_calls:
+            hip.check(getattr(hip.lib, name)(h, *args), name)
+        hip.check(hip.lib.qtts_model_set_final_norm(h, hip.ptr(self.final_norm)), "set_final_norm")
+        hip.check(hip.lib.qtts_model_set_rope(h, hip.ptr(self.cos), hip.ptr(self.sin), self.max_pos), "set_rope")
+        hip.check(hip.lib.qtts_model_set_kv_cache(h, hip.ptr(self.kv_cache), self.num_kv_blocks), "set_kv_cache")
+        nbytes = hip.lib.qtts_model_workspace_bytes(h, t.max_rows, t.max_context)
+        t.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        hip.check(hip.lib.qtts_model_set_workspace(h, hip.ptr(t.workspace), nbytes, t.max_rows, t.max_context), "set_workspace")
+        return t
 
     def forward_logits(self, x, positions, slot_mapping, context_lens, block_tables, max_context, head_packed, vocab,
                        hidden_out, logits_out, row_seq=None):

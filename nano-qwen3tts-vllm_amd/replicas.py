@@ -68,6 +68,9 @@ def replica_main(index: int, device_index: int | None, factory: str, factory_kwa
         return
     res_q.put(("__replica__", index, "ready", None))
     from .sampling_params import SamplingParams
+    # QTTS_OVERLAP_PREFILL=1: an engine that can prefill a new prompt beside the running frames is asked to
+    overlap = os.environ.get("QTTS_OVERLAP_PREFILL", "0") == "1" and getattr(engine, "overlapped_admission", False)
+    admit_kw = {"wait": False} if overlap else {}
     waiting: list = []
     running = True
     while running or engine.streams:
@@ -94,7 +97,8 @@ def replica_main(index: int, device_index: int | None, factory: str, factory_kwa
             _, rid, prompt, text_adds, max_frames, tsp, psp = cmd
             try:
                 engine.add_stream(_to_tensor(prompt), _to_tensor(text_adds), max_frames=max_frames,
-                                  talker_sampling=SamplingParams(**tsp), predictor_sampling=SamplingParams(**psp), sid=rid)
+                                  talker_sampling=SamplingParams(**tsp), predictor_sampling=SamplingParams(**psp), sid=rid,
+                                  **admit_kw)
             except Exception as e:
                 if type(e).__name__ == "NoCapacity" and engine.streams:
                     still.append(cmd)                  # a row / KV blocks come back when a running stream ends

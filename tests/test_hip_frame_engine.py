@@ -255,3 +255,56 @@ def test_step_finishes_a_stream_at_its_frame_budget(tmp_path):
         fe.add_stream(torch.zeros(4, H), torch.zeros(1, H), max_frames=2,
                       talker_sampling=SamplingParams(temperature=1.0, max_tokens=1, do_sample=True, top_k=20))
     fe.exit()
+
+
+def test_prompts_prefilled_beside_the_running_frames_give_the_same_ids(tmp_path):
+    """add_stream(wait=False): the prompt is prefilled on a second HIP stream while the running streams' frames go on,
+    and joins at a frame boundary.  Three newcomers admitted at once (their prefills queue up), one of them cancelled
+    while it waits: every stream's ids equal a run of that stream alone, the running stream is not disturbed, and all
+    KV blocks come back."""
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    cfg, sd, tw, pw, g = fixture_model("sharp")
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(31)
+    H = cfg["talker_config"]["hidden_size"]
+    prompts = [torch.randn(L, H, generator=gen) * 0.5 for L in (9, 300, 40, 17)]
+    texts = [torch.randn(12, H, generator=gen) * 0.3 for _ in prompts]
+    kw = dict(max_streams=4, max_text_frames=16, talker_weights=tw, predictor_weights=pw, num_kvcache_blocks=12,
+              max_num_batched_tokens=1024, codec_eos=None)
+
+    def solo(i, n):
+        fe = FrameEngine(str(tmp_path), **kw)
+        fe.add_stream(prompts[i], texts[i], max_frames=n, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+        out = fe.run_frames(n)[:, 0].tolist()
+        fe.exit()
+        return out
+
+    want = [solo(0, 12), solo(1, 6), solo(2, 6), solo(3, 6)]
+    fe = FrameEngine(str(tmp_path), **kw)
+    free0 = len(fe.talker.scheduler.block_manager.free_block_ids)
+    sp = dict(talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+    a = fe.add_stream(prompts[0], texts[0], max_frames=12, **sp)
+    got = {a: []}
+    ids = {}
+    for f in range(12):
+        if f == 2:
+            for i in (1, 2, 3):
+                ids[i] = fe.add_stream(prompts[i], texts[i], max_frames=6, wait=False, **sp)
+                got[ids[i]] = []
+            assert not fe.streams[ids[1]].active or fe.streams[ids[1]].ready is not None
+            fe.remove_stream(ids[3])                      # leaves while its prefill has not even started
+        for sid, frame in fe.step().items():
+            got[sid].append(frame)
+    while fe.streams:
+        for sid, frame in fe.step().items():
+            got[sid].append(frame)
+    assert got[a] == want[0]
+    assert got[ids[1]] == want[1] and got[ids[2]] == want[2] and got[ids[3]] == []
+    assert len(fe.talker.scheduler.block_manager.free_block_ids) == free0
+    # with nothing running, step() waits for the first prefill instead of returning nothing
+    b = fe.add_stream(prompts[3], texts[3], max_frames=6, wait=False, **sp)
+    frames = []
+    while fe.streams:
+        frames += [fr for fr in fe.step().values()]
+    assert frames == want[3]
+    fe.exit()
