@@ -313,7 +313,10 @@ int qtts_model_forward_logits(qtts_model_t *m, const void *x, const int64_t *pos
  * attention reads the table rows (needs max_context <= 32 unless Hq/Hkv == 4).  Both tables are functions of the
  * weights only: for the code predictor x_table[i] = small_to_mtp_projection(codec_embedding[i].weight) and
  * qkv0_table[i] = qkv_proj(input_layernorm(x_table[i])) of layer 0, built once at load with the library's own
- * GEMMs, so a step returns the same bits as gathering and projecting on the fly
+ * GEMMs, so a step returns the same bits as gathering and projecting on the fly.
+ * positions, slot_mapping, context_lens and block_tables may ALL be NULL: row r is then sequence r with its tokens in KV
+ * block r, every row at context max_context (<= 32; position max_context - 1, slot r * 256 + max_context - 1) - the
+ * burst of a batch whose sequences were given block r each; the attention launches then read no metadata at all.
  * (get_input_embeddings P/models/qwen3_tts_predictor.py:87-99, projection :58-61,106, layer body
  * P/models/qwen3_tts_share.py:96-103,160-176). */
 int qtts_model_forward_logits_gathered(qtts_model_t *m, const void *x_table, const void *qkv0_table,

@@ -1748,7 +1748,11 @@ __device__ __forceinline__ void st_agent(float *p, float v) {
 // behind them is fetched from the argument buffer); `p` repeats them for the host's convenience.
 // IDS: the qkv rows come from a table, row r of the launch is table row p.row_ids[r] (one more dependent request
 // in front of the row loads; everything else is unchanged).
-template <int G, int NG, int TPG = ATT2_SPLIT / NG, bool IDS = false>
+// UNIFORM: every row r is sequence r with its tokens in KV block r, all at the same context length, which arrives
+// as a scalar argument (in a_max_blocks' place; position = context - 1, slot = r * 256 + context - 1): a step of
+// the code predictor's burst in the frame engine.  Nothing but the row ids (IDS) is device data then, so the cached
+// K/V are requested with the wave's first instructions instead of one metadata round trip later.
+template <int G, int NG, int TPG = ATT2_SPLIT / NG, bool IDS = false, bool UNIFORM = false>
 __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_t *__restrict__ a_ctx,
                                                                     const int32_t *__restrict__ a_tables,
                                                                     const int64_t *__restrict__ a_pos,
@@ -1771,19 +1775,19 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
     static_assert(QTTS_KV_BLOCK % SPLIT == 0, "a workgroup's token range must not straddle KV blocks");
     // the row's metadata: four independent requests in one batch, no branch between them (a null slot array reads
     // the context length in its place and is sorted out afterwards)
-    const int blk_all = a_tables[(size_t)row * a_max_blocks + (t0 >> 8)];
+    const int blk_all = UNIFORM ? row : a_tables[(size_t)row * a_max_blocks + (t0 >> 8)];
     // a context beyond what this launch's grid covers (the host's max_context) is cut to it: every split the
     // row counts on exists, so the arrival counter always completes and `out` is always written
-    const int ctx = min(a_ctx[row], a_nsplit * SPLIT);
-    const int slot_raw = (a_slots ? a_slots : a_ctx)[row];
-    long pos = a_pos[row];
+    const int ctx = UNIFORM ? a_max_blocks : min(a_ctx[row], a_nsplit * SPLIT);
+    const int slot_raw = UNIFORM ? row * QTTS_KV_BLOCK + a_max_blocks - 1 : (a_slots ? a_slots : a_ctx)[row];
+    long pos = UNIFORM ? a_max_blocks - 1 : a_pos[row];
     long qrow = IDS ? p.row_ids[row] : row;
     // One wait for the whole batch, the struct's pointers included: without this the compiler moves each request
     // down to its first use, behind the early exits, and the wave pays one round trip after the other.
     asm volatile("" ::"s"(blk_all), "s"(ctx), "s"(slot_raw), "s"(pos), "s"(p.kc), "s"(p.vc), "s"(p.cosT), "s"(p.sinT),
                  "s"(p.qw), "s"(p.kw), "s"(p.out), "s"(qrow));
     if (IDS) qrow = qrow < 0 ? 0 : (qrow >= p.id_rows ? p.id_rows - 1 : qrow);
-    const int slot = a_slots ? slot_raw : -1;
+    const int slot = (UNIFORM || a_slots) ? slot_raw : -1;
     const int Hq = a_Hq, Hkv = a_Hkv;
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     // The G query heads and the new token's K are normalised and rotated once per workgroup, by the first G + 1
@@ -1988,8 +1992,13 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
                                        const int32_t *context_lens, int max_context, float scale, void *out,
                                        int ldo, int B, int Hq, int Hkv, void *partials, int *counters,
                                        hipStream_t s, const int64_t *row_ids = nullptr, int id_rows = 0) {
-    QCHECK(qkv && q_norm_w && k_norm_w && rope_cos && rope_sin && positions && k_cache && v_cache && block_tables &&
-               context_lens && out, "attention_decode_fused: null pointer");
+    // uniform rows (no metadata arrays at all): row r = sequence r in KV block r, every row at context max_context
+    const bool uniform = !positions && !slot_mapping && !block_tables && !context_lens;
+    QCHECK(qkv && q_norm_w && k_norm_w && rope_cos && rope_sin && k_cache && v_cache && out &&
+               (uniform || (positions && block_tables && context_lens)), "attention_decode_fused: null pointer");
+    QCHECK(!uniform || (max_context <= 32 && max_context <= QTTS_KV_BLOCK && Hq / Hkv <= 2),
+           "attention_decode_fused: rows without metadata need max_context <= 32 and at most 2 query heads per KV head");
+    if (uniform) max_blocks = 1;
     QCHECK(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && ldqkv % 8 == 0 && ldqkv >= (Hq + 2 * Hkv) * 128 &&
                ldo >= Hq * 128, "attention_decode_fused: bad shape");
     QCHECK(max_pos > 0 && max_blocks > 0 && max_context > 0 && max_context <= max_blocks * QTTS_KV_BLOCK,
@@ -2012,6 +2021,17 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
     a.counters = counters;
     a.row_ids = row_ids; a.id_rows = id_rows;
     dim3 grid(B, Hkv, ns);
+    if (uniform) {
+        // the context length travels in the max_blocks argument's place
+#define QUNI(G_, IDS_) hipLaunchKernelGGL((attn_decode_fused_kernel<G_, 8, 4, IDS_, true>), grid, dim3(128), 0, s, a.context_lens, \
+                                          a.block_tables, a.positions, a.slots, a.qkv, max_context, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a)
+        QCHECK(!row_ids || id_rows > 0, "attention_decode_fused: row ids without a table size");
+        if (Hq / Hkv == 1) { if (row_ids) QUNI(1, true); else QUNI(1, false); }
+        else { if (row_ids) QUNI(2, true); else QUNI(2, false); }
+#undef QUNI
+        QLAUNCH();
+        return QTTS_OK;
+    }
     if (row_ids) {
         // rows gathered from a table: built for the one-workgroup-per-(row, kv head) variants
         QCHECK(id_rows > 0 && (max_context <= 32 || Hq / Hkv == 4), "attention_decode_fused: gathered rows need max_context <= 32 (got %d)", max_context);
@@ -2853,13 +2873,17 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     if (!m->final_norm || !m->cosT || !m->kv || !m->ws) QFAIL(QTTS_ESTATE, "model_forward: model not fully configured");
     for (const LayerW &L : m->layers)
         if (!L.wqkv) QFAIL(QTTS_ESTATE, "model_forward: layer weights missing");
-    QCHECK(x && positions && hidden_out && (pairs || (context_lens && block_tables)), "model_forward: null pointer");
+    // uniform decode rows: no metadata arrays (row r = sequence r in KV block r at context max_context), see
+    // attention_decode_fused_impl
+    const bool uniform = !pairs && !row_seq && !positions && !slot_mapping && !context_lens && !block_tables;
+    QCHECK(x && hidden_out && (uniform || (positions && (pairs || (context_lens && block_tables)))), "model_forward: null pointer");
+    QCHECK(!uniform || (N <= m->num_blocks && N <= 16), "model_forward: rows without metadata need a KV block each (N=%d)", N);
     // pairs: rows (2i, 2i+1) are the two positions of a fresh sequence i; the head (required) runs on the second rows
     QCHECK(!pairs || (N % 2 == 0 && N <= 16 && !row_seq && !x_ids && head_w), "model_forward: bad 2-position prompt arguments");
     QCHECK(N > 0 && N <= m->ws_rows, "model_forward: N=%d exceeds workspace rows %d", N, m->ws_rows);
     QCHECK(row_seq || N <= QTTS_MAX_DECODE_ROWS, "model_forward: a decode step takes at most %d rows (got %d)", QTTS_MAX_DECODE_ROWS, N);
     QCHECK(max_context > 0 && max_context <= m->ws_ctx, "model_forward: max_context=%d exceeds workspace %d", max_context, m->ws_ctx);
-    QCHECK(pairs || (max_blocks > 0 && max_context <= max_blocks * QTTS_KV_BLOCK), "model_forward: max_context exceeds block table");
+    QCHECK(pairs || uniform || (max_blocks > 0 && max_context <= max_blocks * QTTS_KV_BLOCK), "model_forward: max_context exceeds block table");
     const WsLayout W = ws_layout(m, m->ws_rows, m->ws_ctx);
     bf16_t *qkv = (bf16_t *)(m->ws + W.qkv);
     bf16_t *attn = (bf16_t *)(m->ws + W.attn);

@@ -18,6 +18,8 @@ work for embedding-fed sequences.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import hip
@@ -300,6 +302,7 @@ class FrameEngine:
                                            hip.ptr(pr.e_buf), bs, H, tr.vocab, s()), "predictor_input")
         pr._greedy_bytes, pr._top_k = self.greedy_p, self.top_k
         pr._burst_temps, pr._burst_rng = self.temps_p, self.rng
+        pr._uniform_rows = os.environ.get("QTTS_UNIFORM_BURST", "1") == "1"     # row r = predictor KV block r (_setup_predictor_meta)
         pr._burst_body(bs)
         hip.check(lib.qtts_frame_glue(hip.ptr(tr.codec_embedding), hip.ptr(self.ptab_ptrs), hip.ptr(self.cur_token),
                                       hip.ptr(pr.burst_tokens), bs, hip.ptr(self.text_add),

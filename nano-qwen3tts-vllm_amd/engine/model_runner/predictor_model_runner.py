@@ -246,9 +246,15 @@ class PredictorModelRunner(ModelRunner):
             prev = hip.ptr(self.burst_tokens) + 8 * (step - 1) * bs
             if self.fold and bs <= 16:               # one 16-row tile: the decode kernels (larger batches project per step)
                 xt, qt = self.x_tables[step - 1], self.qkv0_tables[step - 1]
+                if getattr(self, "_uniform_rows", False):
+                    # row r is sequence r in KV block r and every row is at context step + 2: no metadata arrays, the
+                    # attention launches have nothing to wait for before they request K/V
+                    meta = (None, None, None, None, 1)
+                else:
+                    meta = (hip.ptr(st.d("positions")[off:off + bs]), hip.ptr(st.d("slots")[off:off + bs]),
+                            hip.ptr(st.d("ctx")[off:off + bs]), hip.ptr(tables), mb)
                 hip.check(hip.lib.qtts_model_forward_logits_gathered(
-                    self.decoder._h, hip.ptr(xt), hip.ptr(qt), prev, xt.shape[0], hip.ptr(st.d("positions")[off:off + bs]),
-                    hip.ptr(st.d("slots")[off:off + bs]), hip.ptr(st.d("ctx")[off:off + bs]), hip.ptr(tables), mb, step + 2,
+                    self.decoder._h, hip.ptr(xt), hip.ptr(qt), prev, xt.shape[0], *meta, step + 2,
                     bs, hip.ptr(self.h_buf), hip.ptr(self.heads[step]), self.vocab, hip.ptr(self.burst_logits[step]), stream()),
                     "model_forward_logits_gathered")
                 pick(step)
@@ -309,6 +315,7 @@ class PredictorModelRunner(ModelRunner):
         self._greedy_bytes = self._greedy_u8(bs)
         self._top_k = seqs[0].top_k
         self._burst_temps, self._burst_rng = st.d("temps"), st.d("rng")
+        self._uniform_rows = False                   # sequences sit in whatever blocks the block manager gave them
         rows = [s.input_embeds.reshape(-1, s.input_embeds.shape[-1]) for s in seqs]
         self.e_buf[:2 * S].copy_(torch.cat(rows, 0).to(torch.bfloat16), non_blocking=True)
         if self.enforce_eager:

@@ -308,3 +308,29 @@ def test_prompts_prefilled_beside_the_running_frames_give_the_same_ids(tmp_path)
         frames += [fr for fr in fe.step().values()]
     assert frames == want[3]
     fe.exit()
+
+
+def test_burst_steps_without_metadata_arrays_give_the_same_ids(tmp_path, monkeypatch):
+    """In the frame engine row r of the predictor's burst is always sequence r in predictor KV block r at context
+    step + 2, so the burst's decode steps are launched without positions / slots / context lengths / block tables
+    (QTTS_UNIFORM_BURST=1, the default).  Same arithmetic: ids, every step's logits and the predictor's KV cache
+    equal, bit for bit, the launches that read the metadata arrays."""
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    cfg, sd, tw, pw, g = fixture_model("sharp")
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(8)
+    H = cfg["talker_config"]["hidden_size"]
+    prompts = [torch.randn(L, H, generator=gen) * 0.5 for L in (5, 33, 12)]
+    texts = [torch.randn(6, H, generator=gen) * 0.3 for _ in prompts]
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("QTTS_UNIFORM_BURST", flag)
+        fe = FrameEngine(str(tmp_path), max_streams=4, max_text_frames=8, talker_weights=tw, predictor_weights=pw,
+                         num_kvcache_blocks=8, max_num_batched_tokens=1024, codec_eos=None)
+        for p, t in zip(prompts, texts):
+            fe.add_stream(p, t, max_frames=5, talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+        ids = fe.run_frames(5).clone()
+        res[flag] = (ids, fe.pr.burst_logits[:, :3].clone(), fe.pr.decoder.kv_cache[:, :, :3, :17].clone())
+        fe.exit()
+    assert torch.equal(res["1"][0], res["0"][0])
+    assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
