@@ -91,7 +91,7 @@ class Qwen3TTSInterface:
         self.input_embedding_weight = self.input_embedding.weight
         self.predictor_embedding_weights = [t.weight for t in self.predictor_input_embeddings]
         self.processor = _get_processor(model_path)
-        self.speech_tokenizer = None
+        self.speech_tokenizer = self._load_speech_tokenizer()
         self.speaker_encoder = None
         self.talker_llm = self.predictor_llm = None
         self._use_mp_engines = True
@@ -117,6 +117,18 @@ class Qwen3TTSInterface:
         self.do_sample = True            # the reference always samples (T=1.0 talker, T=0.9 predictor, top-k 50)
         self.max_frames = 1024           # explicit stop: the reference has no length guard (ends only on codec EOS)
         self.ignore_eos = False          # benchmarks with random weights: keep generating through codec id 2150
+
+    @staticmethod
+    def _load_speech_tokenizer():
+        """The codec wrapper applications reach through `interface.speech_tokenizer` (codes -> PCM,
+        examples/quick_benchmark.py:66); None when the third-party codec package is not installed, as in the
+        reference (P/interface.py:421-440).  QTTS_SPEECH_TOKENIZER names another codec directory / hub id."""
+        try:
+            from .utils.audio import DEFAULT_CODEC, SpeechTokenizer
+            return SpeechTokenizer(os.environ.get("QTTS_SPEECH_TOKENIZER", DEFAULT_CODEC))
+        except Exception as e:
+            logger.info(f"[interface] speech tokenizer unavailable: {type(e).__name__}: {e}")
+            return None
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, *, cache_dir=None, force_download=False,

@@ -171,3 +171,25 @@ def write_model_dir(path: str, size: str = "tiny", seed: int = 1234, **kw) -> di
         json.dump(cfg, f)
     save_file(make_state_dict(cfg, seed, **kw), os.path.join(path, "model.safetensors"))
     return cfg
+
+
+def write_tokenizer(path: str, text_vocab_size: int = 64) -> None:
+    """A character-level tokenizer in the model directory (`tokenizer.json` + `tokenizer_config.json`, loadable
+    offline by `AutoTokenizer.from_pretrained(path)` as the processor does): the released directories ship a Qwen2
+    BPE tokenizer, which cannot be fetched here.  The chat markers are single ids; lower-cased letters, blank,
+    newline and basic punctuation are ids of their own; everything else is `<unk>`.  All ids stay below the tts
+    special ids at the top of the text vocabulary (make_config)."""
+    from tokenizers import AddedToken, Regex, Tokenizer, models, normalizers, pre_tokenizers
+
+    vocab = {"<unk>": 0, "<|im_start|>": 1, "<|im_end|>": 2, "<pad>": 3}
+    for c in " abcdefghijklmnopqrstuvwxyz.,!?'\n":
+        vocab[c] = len(vocab)
+    assert len(vocab) <= text_vocab_size - 8, "text vocabulary too small for the character set"
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.normalizer = normalizers.Lowercase()
+    tok.pre_tokenizer = pre_tokenizers.Split(Regex("."), behavior="isolated")
+    tok.add_special_tokens([AddedToken(t, special=True, normalized=False) for t in ("<|im_start|>", "<|im_end|>", "<pad>")])
+    os.makedirs(path, exist_ok=True)
+    tok.save(os.path.join(path, "tokenizer.json"))
+    with open(os.path.join(path, "tokenizer_config.json"), "w") as f:
+        json.dump({"tokenizer_class": "PreTrainedTokenizerFast", "unk_token": "<unk>", "pad_token": "<pad>"}, f)

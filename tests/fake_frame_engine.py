@@ -1,0 +1,52 @@
+"""A CPU stand-in for engine.frame_engine.FrameEngine with the surface Qwen3TTSInterface uses (constructor keywords,
+`tr.config.max_model_len`, `max_streams`, `streams`, `capture_all`, `add_stream`, `step`, `remove_stream`, `exit`).
+Frames are deterministic functions of the prompt; a stream ends after `FRAMES` frames, as if the talker had emitted
+the codec EOS id.  Used where the API surface is exercised without a GPU."""
+from types import SimpleNamespace
+
+FRAMES = 12
+
+
+class NoCapacity(RuntimeError):
+    pass
+
+
+class FakeFrameEngine:
+    overlapped_admission = False
+
+    def __init__(self, model_dir, max_streams=8, enforce_eager=False, codec_eos=2150, **kw):
+        self.model_dir, self.max_streams, self.enforce_eager, self.codec_eos = model_dir, max_streams, enforce_eager, codec_eos
+        self.tr = SimpleNamespace(config=SimpleNamespace(max_model_len=1024))
+        self.streams = {}
+        self.captured = False
+        self.kw = kw
+
+    def capture_all(self, max_context=None):
+        self.captured = True
+        return 0
+
+    def add_stream(self, prompt_embeds, text_adds, max_frames, talker_sampling=None, predictor_sampling=None, sid=None,
+                   wait=True):
+        if len(self.streams) >= self.max_streams:
+            raise NoCapacity("all stream rows are taken")
+        assert prompt_embeds.dim() == 2 and text_adds.dim() == 2 and text_adds.shape[1] == prompt_embeds.shape[1]
+        assert prompt_embeds.shape[0] + max_frames + 1 <= 1024, "prompt + frames exceed max_model_len (1024)"
+        key = int(prompt_embeds.float().abs().sum().item() * 7) % 1000
+        self.streams[sid] = SimpleNamespace(key=key, n=0, limit=min(max_frames, FRAMES))
+        return sid
+
+    def remove_stream(self, sid):
+        self.streams.pop(sid, None)
+
+    def step(self):
+        out = {}
+        for sid, s in list(self.streams.items()):
+            if s.n >= s.limit:                      # "codec EOS": the stream ends without yielding this frame
+                del self.streams[sid]
+                continue
+            out[sid] = [(s.key + s.n * 17 + c) % 256 for c in range(16)]
+            s.n += 1
+        return out
+
+    def exit(self):
+        self.streams.clear()
