@@ -733,4 +733,4 @@ def test_swiglu_launches_with_few_tiles_stay_inside_their_output(hip, M, I, K):
         torch.cuda.synchronize()
         assert bool((buf2[:4] == 777.0).all()) and bool((buf2[4 + M:] == 777.0).all())
         wantd = torch.nn.functional.linear(want, wd).float()
-        assert torch.allclose(buf2[4:4 + M].float().cpu(), wantd, atol=2e-2, rtol=2e-2)
+        assert torch.allclose(buf2[4:4 + M].float().cpu(), wantd, atol=6e-2, rtol=2e-2)      # O(5) sums: a bf16 step is 0.03
