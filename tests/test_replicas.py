@@ -86,3 +86,41 @@ def test_rejected_and_failing_streams_end_with_an_error():
 def test_start_up_failure_is_reported():
     with pytest.raises(RuntimeError, match="no engine today"):
         ReplicaPool(1, "fake_replica_engine:broken", {}, start_timeout=120)
+
+
+@pytest.mark.gpu
+def test_two_replica_processes_with_the_real_engine(tmp_path):
+    """Two replica processes, each with its own FrameEngine on the HIP path (both pinned to GPU 0 here: the test box
+    has one), fed four greedy streams through the router: every stream's frames equal a run of that stream on an
+    engine in this process, whichever replica served it."""
+    import json
+    import os
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    from nano_qwen3tts_vllm.sampling_params import SamplingParams
+    from nano_qwen3tts_vllm.utils import synthetic
+    d = str(tmp_path / "model")
+    synthetic.write_model_dir(d, "tiny", seed=11, norm_jitter=0.1, embed_std=0.05, head_sharp=1.0, head_std=0.05)
+    H = synthetic.make_config("tiny")["talker_config"]["hidden_size"]
+    gen = torch.Generator().manual_seed(2)
+    prompts = [torch.randn(L, H, generator=gen) * 0.5 for L in (7, 30, 12, 19)]
+    texts = [torch.randn(8, H, generator=gen) * 0.3 for _ in prompts]
+    tsp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
+    psp = SamplingParams(temperature=0.9, max_tokens=17, do_sample=False)
+    kw = dict(max_streams=2, max_text_frames=16, num_kvcache_blocks=4, max_num_batched_tokens=1024, codec_eos=None)
+    fe = FrameEngine(d, **kw)
+    want = []
+    for p, t in zip(prompts, texts):
+        sid = fe.add_stream(p, t, max_frames=6, talker_sampling=tsp, predictor_sampling=psp)
+        want.append(fe.run_frames(6)[:, 0].tolist())
+        fe.remove_stream(sid)
+    fe.exit()
+    pool = ReplicaPool(2, "nano_qwen3tts_vllm.replicas:frame_engine_factory", dict(model_dir=d, capture=False, **kw),
+                       devices=[0, 0], max_streams_per_replica=2, start_timeout=300)
+    try:
+        rids = [pool.submit(p, t, 6, talker_sampling=tsp, predictor_sampling=psp, request_id=f"s{i}")
+                for i, (p, t) in enumerate(zip(prompts, texts))]
+        assert sorted(r for _, r in pool.placements) == [0, 0, 1, 1]
+        got = [list(pool.frames(rid, timeout=120)) for rid in rids]
+    finally:
+        pool.close()
+    assert got == want
