@@ -164,6 +164,23 @@ def pmc_traffic():
     return None, None
 
 
+def profiler_duration():
+    """(average us, file) of the dominant launch in the committed rocprofv3 kernel trace of this same command
+    (profiles/r02_bench_summary_*.txt, the line of the 256-workgroup grid) - a stored figure, shown beside the live
+    one: the profiler's begin->end timestamps exclude the command processor's ~1 us around a kernel that the
+    events include."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_summary_*.txt")), reverse=True):
+        try:
+            m = re.search(r"grid \(131072, 1\): calls\s+\d+ avg\s+([0-9.]+) us", open(path).read())
+            if m:
+                return float(m.group(1)), "profiles/" + os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
+
+
 def dist_env():
     """(rank, world, local_rank) as torch.distributed.run exports them; a plain `python bench.py` is rank 0 of 1."""
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -407,7 +424,9 @@ def main():
         bytes_frame = algorithmic_bytes_per_frame(cfg, B, mean_ctx, args.weights, folded)
         kmean, kmedian, ksamples = time_dominant_kernel_in_frames(fe, ROOFLINE_FRAMES)
         kbytes = dominant_bytes(fe, B)
-        traffic, traffic_src = pmc_traffic() if args.weights == "bf16" and args.size == "1.7B" and B == 8 else (None, None)
+        stored = args.weights == "bf16" and args.size == "1.7B" and B == 8       # what the stored figures were taken on
+        traffic, traffic_src = pmc_traffic() if stored else (None, None)
+        prof_us, prof_src = profiler_duration() if stored else (None, None)
         out = {
             "metric": "codec tokens/sec at 8 concurrent streams per GPU (RTF alongside), Qwen3-TTS-1.7B",
             "value": value, "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -431,7 +450,7 @@ def main():
                          "achieved": kbytes / kmean / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": kbytes / kmean / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": kbytes, "us_per_launch": kmean * 1e6, "us_per_launch_median": kmedian * 1e6,
-                         "launches_timed": ksamples,
+                         "launches_timed": ksamples, "us_per_launch_profiler": prof_us, "profiler_source": prof_src,
                          "how": "HIP start/stop events bound to that launch of each of the 28 layers (hipExtLaunchKernelGGL on "
                                 "the engine's stream) while frames are generated, right after the timed region"},
         }

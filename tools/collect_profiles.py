@@ -1,6 +1,6 @@
 """Turns the output of tools/refresh_profiles.sh (gpurun_out/refresh/) into the files kept under profiles/.
 
-    python tools/collect_profiles.py [tag]        # tag defaults to v9: r01_bench_line_<tag>.json ...
+    python tools/collect_profiles.py [tag]        # tag defaults to v1: r02_bench_line_<tag>.json ...
 """
 import collections
 import csv
@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = os.path.join(ROOT, "gpurun_out", "refresh")
-P = os.path.join(ROOT, "profiles")
+P = os.environ.get("QTTS_PROFILES_OUT", os.path.join(ROOT, "profiles"))     # refresh_profiles.sh collects on the box
 
 
 def last_json(path):
@@ -22,29 +22,35 @@ def last_json(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "v9"
-    for old in glob.glob(os.path.join(P, "r01_bench_*_v*")):
+    tag = sys.argv[1] if len(sys.argv) > 1 else "v1"
+    os.makedirs(P, exist_ok=True)
+    for old in glob.glob(os.path.join(P, "r02_bench_*_v*")):
         os.remove(old)
     bench = last_json(os.path.join(R, "bench_line.json"))
-    json.dump(bench, open(os.path.join(P, f"r01_bench_line_{tag}.json"), "w"))
-    header = (f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline   (round 1, MI355X; "
-              f"bench line of the same build without the profiler: profiles/r01_bench_line_{tag}.json)")
+    json.dump(bench, open(os.path.join(P, f"r02_bench_line_{tag}.json"), "w"))
+    header = (f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline   (round 2, MI355X; "
+              f"bench line of the same build without the profiler: profiles/r02_bench_line_{tag}.json)")
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "profile_summary.py"), os.path.join(R, "trace", "vm"),
-                    os.path.join(P, f"r01_bench_summary_{tag}.txt"), header], check=True, stdout=subprocess.DEVNULL)
-    shutil.copy(glob.glob(os.path.join(R, "trace", "vm", "*_kernel_stats.csv"))[0], os.path.join(P, f"r01_bench_kernel_stats_{tag}.csv"))
+                    os.path.join(P, f"r02_bench_summary_{tag}.txt"), header], check=True, stdout=subprocess.DEVNULL)
+    shutil.copy(glob.glob(os.path.join(R, "trace", "vm", "*_kernel_stats.csv"))[0], os.path.join(P, f"r02_bench_kernel_stats_{tag}.csv"))
     for name in ("fetch", "write"):
         shutil.copy(glob.glob(os.path.join(R, f"pmc_{name}", "vm", "*counter_collection.csv"))[0],
-                    os.path.join(P, f"r01_pmc_{name}_counter_collection.csv"))
-    for f in ("api_quick_benchmark", "api_batch_async_fused", "api_batch_async_workers", "api_batch_async_fused_sampling",
-              "api_quick_benchmark_sampling"):
+                    os.path.join(P, f"r02_pmc_{name}_counter_collection.csv"))
+    for f in ("bench_2rank_rehearsal", "api_quick_benchmark", "api_batch_async_fused", "api_batch_async_workers",
+              "api_batch_async_fused_sampling", "api_quick_benchmark_sampling"):
         src = os.path.join(R, f + ".json")
         if os.path.exists(src):
-            json.dump(last_json(src), open(os.path.join(P, f"r01_{f}.json"), "w"))
+            json.dump(last_json(src), open(os.path.join(P, f"r02_{f}.json"), "w"))
 
     def med(name, counter, match):
         f = glob.glob(os.path.join(R, name, "**", "*counter_collection.csv"), recursive=True)[0]
         v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if match in r["Kernel_Name"] and r["Counter_Name"] == counter]
         return statistics.median(v), len(v)
+    if os.path.exists(os.path.join(R, "bench_overlap1.json")):
+        json.dump({"source": "python bench.py (arrivals workload: 8 streams 50 ms apart, 125 frames each), same box, same build",
+                   "prefill between two frames (default)": bench["arrivals"],
+                   "prefill on a second stream beside the frames (QTTS_OVERLAP_PREFILL=1)": last_json(os.path.join(R, "bench_overlap1.json"))["arrivals"]},
+                  open(os.path.join(P, "r02_arrivals_admission_ab.json"), "w"), indent=1)
     fs, n = med("pmc_fetch", "FETCH_SIZE", "linear2_kernel<8, 1, true, 1")
     ws, _ = med("pmc_write", "WRITE_SIZE", "linear2_kernel<8, 1, true, 1")
     json.dump({"kernel": "linear2_kernel<8,1,true,1> (talker RMSNorm + gate/up GEMM + SwiGLU launch, M=8, 1.7B shape)",
@@ -52,7 +58,7 @@ def main():
                "fetch_size_kib_median": fs, "write_size_kib_median": ws,
                "correction": "HBM bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 tallies 128-B streaming read requests at 64 B)",
                "traffic_bytes_per_launch": 2 * fs * 1024 + ws * 1024, "algorithmic_bytes_per_launch": 50462720,
-               "launches_sampled": n}, open(os.path.join(P, "r01_pmc_traffic.json"), "w"), indent=1)
+               "launches_sampled": n}, open(os.path.join(P, "r02_pmc_traffic.json"), "w"), indent=1)
 
     rows_txt = open(os.path.join(R, "rows.txt")).read()
     us = {}
@@ -76,7 +82,7 @@ def main():
             t = us[which[k]]
             e.update(us_per_launch=t, mfma_utilisation=b / (t * 1e-6 * 2.4e9 * 1024), tflops_issued=b / 16 * 16384 / (t * 1e-6) / 1e12)
         out["kernels"][k] = e
-    json.dump(out, open(os.path.join(P, "r01_pmc_mfma.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(P, "r02_pmc_mfma.json"), "w"), indent=1)
 
     sweep = []
     for S in (1, 8, 16, 32, 64, 128):
@@ -84,11 +90,11 @@ def main():
         sweep.append({"streams_per_gpu": S, "codec_tokens_per_s": round(x["value"]), "ms_per_frame": round(x["ms_per_step"], 3),
                       "rtf": round(x["rtf"], 4), "frame_roofline_frac": round(x["frame_roofline"]["frac"], 3), "steps": x["steps"]})
     json.dump({"note": "python bench.py --streams S (1 GPU, MI355X, 1.7B shapes, greedy); the contract line is S=8", "sweep": sweep},
-              open(os.path.join(P, "r01_streams_sweep.json"), "w"), indent=1)
+              open(os.path.join(P, "r02_streams_sweep.json"), "w"), indent=1)
 
     pb = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prefill_breakdown.py"), os.path.join(R, "prefill_trace")],
                         capture_output=True, text=True, check=True).stdout
-    with open(os.path.join(P, "r01_prefill.txt"), "w") as fo:
+    with open(os.path.join(P, "r02_prefill.txt"), "w") as fo:
         fo.write("tools/microbench.py prefill (talker 1.7B shapes, one prompt per call, wall time of FrameEngine.add_stream, MI355X):\n")
         fo.write(open(os.path.join(R, "prefill.txt")).read() + "\nrocprofv3 --kernel-trace of the same, 200 tokens:\n" + pb)
         fo.write("\ntools/microbench.py rows (prompt GEMMs alone; cold = 28 weight matrices in turn, hot = one):\n" + rows_txt)
@@ -97,7 +103,7 @@ def main():
           "frame frac", round(bench["frame_roofline"]["frac"], 3), "cpu", round(bench["cpu_baseline"]["value"]))
     for s in sweep:
         print(s)
-    for f in sorted(glob.glob(os.path.join(P, "r01_api_*.json"))):
+    for f in sorted(glob.glob(os.path.join(P, "r02_api_*.json"))):
         d = json.load(open(f))
         print(os.path.basename(f), {k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()
                                     if k in ("rtf", "first_frame_ms_p50", "first_chunk_ms_p50", "inter_chunk_ms_p50", "inter_chunk_ms_p99", "rtf_per_stream_p50")})
