@@ -16,7 +16,6 @@ from __future__ import annotations
 
 import asyncio
 import contextlib
-import importlib.util
 import io
 import json
 import os
@@ -39,13 +38,46 @@ def make_model_dir(path: str) -> str:
     return path
 
 
+def load_reference_script(name: str, as_dir: str, module_name: str):
+    """The reference's examples/<name>, compiled from its text as it stands and executed as a module whose
+    `__file__` lies in `as_dir`: a script that creates directories next to itself (server.py: voices/, debug/) then
+    does so in a scratch directory, and no bytecode cache is written beside the source — nothing under
+    /root/reference is touched."""
+    path = os.path.join(REF_EXAMPLES, name)
+    with open(path) as f:
+        code = compile(f.read(), os.path.join(as_dir, name), "exec", dont_inherit=True)
+    mod = types.ModuleType(module_name)
+    mod.__file__ = os.path.join(as_dir, name)
+    sys.modules[module_name] = mod
+    exec(code, mod.__dict__)
+    return mod
+
+
 def codec_stand_in() -> types.ModuleType:
-    """`qwen_tts` as far as the scripts and the wrapper touch it: a tokenizer whose decode returns 1920 samples of
-    silence per frame at 24 kHz (12.5 Hz frames)."""
+    """`qwen_tts` as far as the scripts and the wrappers touch it: a tokenizer whose decode returns 1920 samples of
+    silence per frame at 24 kHz (12.5 Hz frames), with a `.model.decoder` module of the same behaviour."""
     import numpy as np
+    import torch
+
+    class Decoder(torch.nn.Module):
+        total_upsample = 1920
+
+        def forward(self, codes):                                  # [B, 16, T] ids -> [B, 1, T * 1920]
+            return torch.zeros(codes.shape[0], 1, codes.shape[-1] * self.total_upsample)
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.decoder = Decoder()
+
+        def get_output_sample_rate(self):
+            return 24000
 
     class Qwen3TTSTokenizer:
         sample_rate = 24000
+
+        def __init__(self):
+            self.model = Model()
 
         @classmethod
         def from_pretrained(cls, name, **kw):
@@ -159,9 +191,7 @@ def run_reference_callers(model_dir: str, out_dir: str) -> dict:
     try:
         calls: list = []
         with recording(calls), contextlib.redirect_stdout(io.StringIO()) as out:
-            spec = importlib.util.spec_from_file_location("ref_quick_benchmark", os.path.join(REF_EXAMPLES, "quick_benchmark.py"))
-            qb = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(qb)
+            qb = load_reference_script("quick_benchmark.py", out_dir, "ref_quick_benchmark")
             avg_time, avg_rtf = qb.benchmark_nano_vllm(model_dir, num_runs=2)
         assert avg_time > 0 and avg_rtf > 0 and "Avg RTF" in out.getvalue()
         result["quick_benchmark"] = calls
@@ -183,11 +213,102 @@ def run_reference_callers(model_dir: str, out_dir: str) -> dict:
     return result
 
 
+def run_reference_server(model_dir: str, scratch: str) -> dict:
+    """`/root/reference/examples/server.py` as it stands, served in-process (starlette's TestClient drives the ASGI
+    app: lifespan start-up with its 1 + 16 warm-up requests, GET /health, /voices, /, POST /v1/audio/speech, lifespan
+    shutdown).  Returns {"interface": [calls...], "codec": {constructor keywords, methods used}, "http": [...]}.
+    Stand-ins as in run_reference_callers; the codec wrapper is the product's class with the device the server
+    hard-wires ("cuda:0") replaced by "cpu", since there is no GPU where this runs."""
+    from starlette.testclient import TestClient
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fake_frame_engine
+    from nano_qwen3tts_vllm.engine import frame_engine as FE
+    os.makedirs(scratch, exist_ok=True)
+    stand_ins = codec_stand_in()
+    saved_modules = {k: sys.modules.get(k) for k in stand_ins}
+    sys.modules.update(stand_ins)
+    import importlib
+    import nano_qwen3tts_vllm.utils.speech_tokenizer_cudagraph as W
+    W = importlib.reload(W)                                 # picks the stand-in codec package up
+    saved_engine, real_wrapper = FE.FrameEngine, W.SpeechTokenizerCUDAGraph
+    saved_env = {k: os.environ.get(k) for k in ("QWEN3_TTS_MODEL_PATH", "DEBUG_SAVE_AUDIO")}
+    codec = {"constructor": None, "methods": set()}
+
+    class RecordedWrapper(real_wrapper):
+        def __init__(self, *a, **k):
+            codec["constructor"] = {"args": list(a), "kwargs": dict(k)}
+            k["device"] = "cpu"
+            super().__init__(*a, **k)
+
+        def __getattribute__(self, name):
+            if name in ("decode", "chunked_decode", "decode_window_batched", "decode_codec_ids"):
+                codec["methods"].add(name)
+            return super().__getattribute__(name)
+
+    W.SpeechTokenizerCUDAGraph = RecordedWrapper
+    FE.FrameEngine = fake_frame_engine.FakeFrameEngine
+    os.environ["QWEN3_TTS_MODEL_PATH"] = model_dir
+    os.environ["DEBUG_SAVE_AUDIO"] = "0"
+    calls: list = []
+    http = []
+    try:
+        with recording(calls):
+            srv = load_reference_script("server.py", scratch, "ref_server")
+            with TestClient(srv.app) as client:
+                for path in ("/health", "/voices", "/"):
+                    r = client.get(path)
+                    http.append({"request": "GET " + path, "status": r.status_code, "json": r.json()})
+                r = client.post("/v1/audio/speech", json={"text": "Hello there.", "language": "English", "speaker": "Vivian"})
+                http.append({"request": "POST /v1/audio/speech", "status": r.status_code,
+                             "content_type": r.headers["content-type"].split(";")[0], "sample_rate": r.headers.get("sample-rate"),
+                             "pcm16_bytes": len(r.content)})
+                r = client.post("/v1/audio/speech", json={"text": ""})
+                http.append({"request": "POST /v1/audio/speech (empty text)", "status": r.status_code})
+    finally:
+        FE.FrameEngine = saved_engine
+        W.SpeechTokenizerCUDAGraph = real_wrapper
+        sys.modules.pop("ref_server", None)
+        for k, v in saved_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        for k, v in saved_modules.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        importlib.reload(W)
+    codec["methods"] = sorted(codec["methods"])
+    return {"interface": calls, "codec": codec, "http": http}
+
+
+def run_reference_loops() -> dict:
+    """The reference's orchestrator loops (/root/reference/nano-qwen3tts-vllm/zmq/engine_loop_mp.py:27-158, stdlib
+    only) driven by the scripted scenario of tests/loop_scenario.py: the messages they put on the per-request queues."""
+    import logging
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import loop_scenario
+    path = "/root/reference/nano-qwen3tts-vllm/zmq/engine_loop_mp.py"
+    with open(path) as f:
+        code = compile(f.read(), "<reference zmq/engine_loop_mp.py>", "exec", dont_inherit=True)
+    mod = types.ModuleType("ref_engine_loop_mp")
+    exec(code, mod.__dict__)
+    logging.disable(logging.CRITICAL)
+    try:
+        return loop_scenario.drive(mod)
+    finally:
+        logging.disable(logging.NOTSET)
+
+
 if __name__ == "__main__":
     import tempfile
     sys.path.insert(0, ROOT)
     d = make_model_dir(tempfile.mkdtemp(prefix="qtts_callers_"))
     rec = run_reference_callers(d, tempfile.mkdtemp())
+    rec["server"] = run_reference_server(d, tempfile.mkdtemp())
     with open(GOLDEN, "w") as f:
         json.dump(rec, f, indent=1)
     print(GOLDEN, {k: len(v) for k, v in rec.items()})
+    with open(os.path.join(ROOT, "tests", "golden", "loop_messages.json"), "w") as f:
+        json.dump(run_reference_loops(), f, indent=1)

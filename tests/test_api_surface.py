@@ -214,3 +214,24 @@ def test_interface_rejects_missing_path_and_front_end(model_dir):
         iface.create_voice_clone_prompt(ref_audio="ref.wav", ref_text="hello")
     with pytest.raises(AssertionError):
         Qwen3TTSInterface(model_dir, tensor_parallel_size=2)
+
+
+def test_orchestrator_loops_put_the_reference_messages_on_the_request_queues():
+    """tests/golden/loop_messages.json holds what the reference's run_talker_loop_mp / run_predictor_loop_mp
+    (zmq/engine_loop_mp.py:27-158) put on the per-request queues in the scripted scenario of tests/loop_scenario.py
+    (written by oracle/ref_callers.py): ("talker", "token", {token_ids, hidden_states}), ("talker", "done", {}),
+    ("predictor", "token", {token_ids}); outputs of a closed request dropped; a failing step retried; the worker not
+    asked while nobody is ready.  This package's loops must produce the same, message for message."""
+    import json
+    import logging
+    import loop_scenario
+    from nano_qwen3tts_vllm.zmq import engine_loop_mp
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "loop_messages.json")))
+    logging.disable(logging.CRITICAL)
+    try:
+        got = loop_scenario.drive(engine_loop_mp)
+    finally:
+        logging.disable(logging.NOTSET)
+    assert got == want
+    assert want["talker"]["queues"]["b"][-1] == ["talker", "done", {}]
+    assert want["talker"]["idle_calls"] == 0 and want["talker"]["client_calls"] == 5

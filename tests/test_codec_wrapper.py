@@ -11,13 +11,14 @@ from nano_qwen3tts_vllm.utils import speech_tokenizer_cudagraph as stc
 
 UP = 8          # samples per frame of the stand-in
 RF = 4          # frames of left context the stand-in looks at
+VOCAB = 128     # rows of the stand-in's code tables: ids handed to it must be below this
 
 
 class CausalDecoder(torch.nn.Module):
     """codes [B,16,T] -> wav [B,1,T*UP]; frame t depends on frames t-RF..t only."""
     total_upsample = UP
 
-    def __init__(self, vocab=128, width=32):
+    def __init__(self, vocab=VOCAB, width=32):
         super().__init__()
         g = torch.Generator().manual_seed(7)
         self.emb = torch.nn.Parameter(torch.randn(16, vocab, width, generator=g) * 0.3)
@@ -57,7 +58,7 @@ class StubTokenizer:
 
 
 def _frames(T, seed=0):
-    return torch.randint(0, 128, (T, 16), generator=torch.Generator().manual_seed(seed))
+    return torch.randint(0, VOCAB, (T, 16), generator=torch.Generator().manual_seed(seed))
 
 
 def test_missing_codec_package_is_an_import_error():

@@ -143,3 +143,35 @@ def test_interface_front_end_builds_the_same_prompts(fe):
         iface._prep_voice_clone("x", "English", None, None, False, dict(vc, ref_text=None), False)
     with pytest.raises(NotImplementedError):
         iface._prep_voice_clone("x", "English", "ref.wav", "words", False, None, True)
+
+
+@pytest.mark.gpu
+def test_interface_front_end_on_the_gpu_matches_the_reference_fixtures(fe):
+    """On a GPU box the API object builds its prompts on the device (fp32 gathers + the text-projection MLP through
+    torch's fp32 GEMM): the same fixture requests, compared with the reference's CPU results.  Gathered rows are
+    exact; rows that went through the MLP may differ by the GEMM's summation order — tolerance 1e-5 (absolute and
+    relative) on O(0.1) values; masks and lengths exact."""
+    from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
+    g = fe["g"]
+    iface = Qwen3TTSInterface(fe["dir"])
+    assert iface.device.type == "cuda"
+    iface.processor = fe["processor"]
+
+    def close(got, name):
+        emb, tail, pad, mask = [t.cpu() for t in got]
+        assert emb.dtype == torch.float32
+        for t, key in ((emb, "_embeds"), (tail, "_tail"), (pad, "_pad")):
+            want = g[name + key]
+            assert t.shape == want.shape, (name, key)
+            assert np.allclose(t.numpy(), want, atol=1e-5, rtol=1e-5), (name, key, float(np.abs(t.numpy() - want).max()))
+        assert np.array_equal(mask.numpy(), g[name + "_mask"]), name
+
+    close(iface._prep_custom_voice("Hello there, world.", "Auto", "", "A calm low voice", True), "design_ns")
+    close(iface._prep_custom_voice("Hello there, world.", "English", "", "A calm low voice", False), "design_stream")
+    spk = torch.from_numpy(g["clone_spk"])
+    vc = {"ref_code": None, "ref_spk_embedding": spk, "x_vector_only_mode": True, "icl_mode": False}
+    close(iface._prep_voice_clone("Clone this voice please.", None, None, None, False, vc, True), "clone_xvec")
+    vc = {"ref_code": torch.from_numpy(g["clone_icl_short_code"]), "ref_spk_embedding": spk, "x_vector_only_mode": False,
+          "icl_mode": True, "ref_text": "Reference words."}
+    close(iface._prep_voice_clone("Clone this voice please.", "English", None, None, False, vc, False), "clone_icl_short")
+    iface.shutdown()

@@ -275,8 +275,9 @@ def test_frame_loop_ids_match_reference_fixture(setup):
     pred.exit()
 
 
-@pytest.mark.parametrize("size", ["1.7B", "0.6B"])
-def test_full_size_frames_match_oracle(size, tmp_path):
+@pytest.mark.parametrize("size,weights,prompt_lens", [("1.7B", "bf16", (9, 40)), ("0.6B", "bf16", (9, 40)),
+                                                      ("1.7B", "bf16", (130, 270)), ("1.7B", "fp8", (130, 270))])
+def test_full_size_frames_match_oracle(size, weights, prompt_lens, tmp_path, monkeypatch):
     """The released checkpoints' shapes (28 + 5 layers; 1.7B: hidden 2048 with the 2048 -> 1024 projection in front of
     the predictor, 0.6B: hidden 1024, no projection), random weights with spread-out heads, 2 streams (prompts of 9
     and 40 tokens) x 3 frames through the frame engine, against the CPU oracle on the same weights and the same
@@ -286,8 +287,13 @@ def test_full_size_frames_match_oracle(size, tmp_path):
     by 0.2 bf16 steps on average and 17 at most, and 1 of its 96 arg-max ids lies more than 8 steps below the plain
     run's winner.  That distance is the yardstick: the HIP path's logits must be no farther from the oracle's than
     1.5 times it on average (twice at most), at most 2 of the 96 picks may lie more than 8 bf16 steps below the
-    oracle's winner, and every pick with a clear winner (at least 70 % of them) must be the oracle's arg-max."""
+    oracle's winner, and every pick with a clear winner (at least 70 % of them) must be the oracle's arg-max.
+    Prompts of 130 and 270 tokens (voice-clone length: the prompt GEMMs with rows stationary in registers, the K-split
+    down projection, the MFMA prompt attention, a second KV block) run the same check through the prompt path; with
+    `weights="fp8"` the engine stores the layer GEMM weights as e4m3 with a power-of-two row scale and the oracle runs
+    on exactly those dequantised weights, so the same bounds apply (the quantisation itself is not judged here)."""
     from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    monkeypatch.setenv("QTTS_WEIGHT_DTYPE", weights)
     cfg = synthetic.make_config(size)
     sd = synthetic.make_state_dict(cfg, seed=31, norm_jitter=0.1, embed_std=0.05, head_sharp=1.0, head_std=0.05)
     tw, pw = synthetic.split_state_dict(sd)
@@ -295,7 +301,7 @@ def test_full_size_frames_match_oracle(size, tmp_path):
     json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
     H, S, NF = cfg["talker_config"]["hidden_size"], 2, 3
     gen = torch.Generator().manual_seed(17)
-    prompts = [torch.randn(L, H, generator=gen) * 0.5 for L in (9, 40)]
+    prompts = [torch.randn(L, H, generator=gen) * 0.5 for L in prompt_lens]
     text_adds = torch.randn(S, NF, H, generator=gen) * 0.3
     fe = FrameEngine(str(tmp_path), max_streams=S, max_text_frames=NF + 1, talker_weights=tw, predictor_weights=pw,
                      num_kvcache_blocks=4, max_num_batched_tokens=1024, codec_eos=None)
@@ -311,7 +317,11 @@ def test_full_size_frames_match_oracle(size, tmp_path):
         for i in range(S):
             t_logits[i].append(fe.tr.logits[i].float().cpu())      # the talker step that opens frame f + 1
     got = torch.stack(got, 1)
+    assert fe.tr.decoder.weight_dtype == weights and fe.pr.decoder.weight_dtype == weights
     fe.exit()
+    if weights == "fp8":                                            # the oracle sees the weights the kernels multiply by
+        tw = {k: (O.quantize_fp8_rows(v)[2] if "_proj.weight" in k else v) for k, v in tw.items()}
+        pw = {k: (O.quantize_fp8_rows(v)[2] if "_proj.weight" in k else v) for k, v in pw.items()}
     tc, pc = oracle_cfgs(cfg)
     r = O.frame_loop_logits(tw, tc, pw, pc, prompts, text_adds, NF, forced=got)
     with O.other_summation_order():
@@ -320,8 +330,8 @@ def test_full_size_frames_match_oracle(size, tmp_path):
     gp = torch.stack(p_logits, 1)                                   # [S,NF,15,Vp]
     for name, mine, ref, alt in (("talker", gt, r["t_logits"], ra["t_logits"]), ("predictor", gp, r["p_logits"], ra["p_logits"])):
         d, noise = ulp_distance(mine, ref), ulp_distance(alt, ref)
-        print(f"[logits] {size} {name}: HIP within {float(d.max()):.1f} bf16 steps of the oracle (mean {float(d.mean()):.3f}); the "
+        print(f"[logits] {size} {weights} prompts {prompt_lens} {name}: HIP within {float(d.max()):.1f} bf16 steps of the oracle (mean {float(d.mean()):.3f}); the "
               f"oracle with re-ordered sums within {float(noise.max()):.1f} (mean {float(noise.mean()):.3f})")
         assert float(d.mean()) <= 1.5 * float(noise.mean()) + 0.02 and float(d.max()) <= 2.0 * float(noise.max()) + 2.0
-    check_frames(got, tw, tc, pw, pc, prompts, text_adds, f"frame engine at {size} shapes", tol_ulps=8.0, min_binding=0.7,
+    check_frames(got, tw, tc, pw, pc, prompts, text_adds, f"frame engine at {size} shapes, {weights} weights, prompts {prompt_lens}", tol_ulps=8.0, min_binding=0.7,
                  max_unacceptable=2, oracle_result=r)
