@@ -135,7 +135,11 @@ class FrameEngine:
                                  f"sampler default, P/layers/sampler.py:15); build the engine with another top_k to change it")
         L = prompt_embeds.shape[-2]
         total = L + max_frames + 1
-        assert total <= self.tr.config.max_model_len, "prompt + frames exceed max_model_len (1024)"
+        if total > self.tr.config.max_model_len:
+            raise ValueError(f"prompt of {L} tokens + {max_frames} frames exceed max_model_len={self.tr.config.max_model_len}")
+        if prompt_embeds.shape[-1] != self.H or text_adds.dim() != 2 or text_adds.shape[-1] != self.H or text_adds.shape[0] < 1:
+            raise ValueError(f"prompt_embeds [L,{self.H}] and text_adds [F>=1,{self.H}] expected, got "
+                             f"{tuple(prompt_embeds.shape)} and {tuple(text_adds.shape)}")
         seq = Sequence([], input_embeds=prompt_embeds.reshape(1, L, -1), sampling_params=tsp, request_id=sid)
         bm = self.talker.scheduler.block_manager
         need = (total + 255) // 256

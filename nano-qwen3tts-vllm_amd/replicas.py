@@ -150,6 +150,7 @@ class ReplicaPool:
         self._sinks: dict[str, "queue.Queue"] = {}       # per request: where its frames go, until the consumer is done
         self._live: set[str] = set()                       # requests waiting in the router or running on a replica
         self._backlog: list = []
+        self._dead: set[int] = set()                       # replicas whose process has gone away
         self._closed = False
         self.placements: list[tuple[str, int]] = []        # (request id, replica) in admission order
         for p in self._procs:
@@ -170,7 +171,10 @@ class ReplicaPool:
 
     # ---------------------------------------------------------------- routing
     def _pick(self) -> int | None:
-        best = min(range(self.n), key=lambda i: (self._load[i], i))
+        alive = [i for i in range(self.n) if i not in self._dead]
+        if not alive:
+            return None
+        best = min(alive, key=lambda i: (self._load[i], i))
         return best if self._load[best] < self.cap else None
 
     def _place_locked(self):
@@ -226,6 +230,7 @@ class ReplicaPool:
             except queue.Empty:
                 if self._closed:
                     return
+                self._reap()
                 continue
             if item[0] == "__replica__":
                 continue
@@ -243,6 +248,34 @@ class ReplicaPool:
             if sink is not None:
                 sink.put((frame, reason))
 
+    def _reap(self):
+        """A replica process that has gone away (crash, kill) takes its streams with it: they end with an error
+        instead of leaving their consumers waiting, the router stops placing on it, and what waits in the router
+        fails too once no replica is left."""
+        ended = []
+        with self._lock:
+            for i, p in enumerate(self._procs):
+                if i in self._dead or p.is_alive():
+                    continue
+                self._dead.add(i)
+                for rid in [r for r, w in self._where.items() if w == i]:
+                    self._where.pop(rid)
+                    self._live.discard(rid)
+                    ended.append((rid, f"replica {i} died (exit code {p.exitcode})"))
+                self._load[i] = 0
+            if len(self._dead) == self.n:
+                for msg in self._backlog:
+                    if msg[1] in self._live:
+                        self._live.discard(msg[1])
+                        ended.append((msg[1], "no replica left"))
+                self._backlog.clear()
+            else:
+                self._place_locked()
+            sinks = [(self._sinks.get(rid), reason) for rid, reason in ended]
+        for sink, reason in sinks:
+            if sink is not None:
+                sink.put((_END, reason))
+
     # ---------------------------------------------------------------- consumers
     def frames(self, request_id: str, timeout: float | None = 120.0):
         """Generator over the stream's 16-id frames, in order; ends when the replica finishes the stream."""
@@ -251,7 +284,10 @@ class ReplicaPool:
             return
         try:
             while True:
-                frame, reason = sink.get(timeout=timeout)
+                try:
+                    frame, reason = sink.get(timeout=timeout)
+                except queue.Empty:
+                    raise TimeoutError(f"stream {request_id}: no frame for {timeout} s") from None
                 if frame is _END:
                     if reason and reason not in ("finished", "cancelled"):
                         raise RuntimeError(f"stream {request_id}: {reason}")

@@ -15,8 +15,9 @@ class _S:
 
 
 class FakeEngine:
-    def __init__(self, tag=0, max_streams=2, step_seconds=0.002, fail_on=None):
+    def __init__(self, tag=0, max_streams=2, step_seconds=0.002, fail_on=None, die_on=None):
         self.tag, self.max_streams, self.step_seconds, self.fail_on = tag, max_streams, step_seconds, fail_on
+        self.die_on = die_on
         self.streams = {}
         self.visible = os.environ.get("HIP_VISIBLE_DEVICES")
 
@@ -37,6 +38,8 @@ class FakeEngine:
         for sid, s in list(self.streams.items()):
             if self.fail_on is not None and s.key == self.fail_on:
                 raise RuntimeError("injected engine failure")
+            if self.die_on is not None and s.key == self.die_on:
+                os._exit(17)                               # the whole replica process goes away mid-stream
             dev = int(self.visible) if self.visible not in (None, "") else -1
             out[sid] = [s.key, s.n, dev, self.tag] + [0] * 12
             s.n += 1

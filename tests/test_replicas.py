@@ -83,6 +83,28 @@ def test_rejected_and_failing_streams_end_with_an_error():
         pool.close()
 
 
+def test_a_replica_process_that_dies_ends_its_streams_and_is_routed_around():
+    """Replica 0's process exits in the middle of a stream (key 7 kills whichever replica serves it): that stream ends
+    with an error naming the replica, the other replica keeps serving, and later requests go to the survivor only."""
+    pool = ReplicaPool(2, FACTORY, dict(max_streams=2, die_on=7, step_seconds=0.01), devices=[None, None],
+                       max_streams_per_replica=2, start_timeout=120)
+    try:
+        other = pool.submit(_prompt(3), torch.zeros(1, 8), max_frames=400, request_id="long")   # on replica 0, dies with it
+        survivor = pool.submit(_prompt(4), torch.zeros(1, 8), max_frames=30, request_id="ok")   # on replica 1
+        with pytest.raises(RuntimeError, match="replica 0 died"):
+            list(pool.generate(_prompt(7), torch.zeros(1, 8), max_frames=50, request_id="killer"))      # least loaded: replica 0
+        with pytest.raises(RuntimeError, match="replica 0 died"):
+            list(pool.frames(other))
+        assert len(list(pool.frames(survivor))) == 30
+        assert dict(pool.placements)["killer"] == 0 and dict(pool.placements)["ok"] == 1
+        for i in range(3):                                                             # only replica 1 is left
+            assert len(list(pool.generate(_prompt(20 + i), torch.zeros(1, 8), max_frames=3, request_id=f"after{i}"))) == 3
+            assert dict(pool.placements)[f"after{i}"] == 1
+        assert pool.load() == [0, 0]
+    finally:
+        pool.close()
+
+
 def test_start_up_failure_is_reported():
     with pytest.raises(RuntimeError, match="no engine today"):
         ReplicaPool(1, "fake_replica_engine:broken", {}, start_timeout=120)

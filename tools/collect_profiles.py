@@ -28,7 +28,7 @@ def main():
         os.remove(old)
     bench = last_json(os.path.join(R, "bench_line.json"))
     json.dump(bench, open(os.path.join(P, f"r02_bench_line_{tag}.json"), "w"))
-    header = (f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline   (round 2, MI355X; "
+    header = (f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline   (MI355X; "
               f"bench line of the same build without the profiler: profiles/r02_bench_line_{tag}.json)")
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "profile_summary.py"), os.path.join(R, "trace", "vm"),
                     os.path.join(P, f"r02_bench_summary_{tag}.txt"), header], check=True, stdout=subprocess.DEVNULL)
