@@ -121,12 +121,42 @@ class FrameEngine:
         wait=False (serving loops): the row and the KV blocks are reserved and the call returns; the prefill runs on a
         second HIP stream BESIDE the frames of the running streams instead of between two of them, and the stream
         joins the batch at the first frame boundary after it has finished (one prefill at a time, in arrival order).
-        Same launches, same ids either way."""
-        row = next((i for i, s in enumerate(self.rows) if s is None), None)
-        if row is None:
-            raise NoCapacity("all stream rows are taken")
-        sid = sid or f"stream-{self._next_sid}"
-        self._next_sid += 1
+        Same launches, same ids either way.
+        Raises NoCapacity (no free row / KV blocks now: try again when a stream has ended) or ValueError (can never
+        be served: too long, wrong shapes, a top_k the graphs were not captured for)."""
+        s = self._reserve(prompt_embeds, text_adds, max_frames, talker_sampling, predictor_sampling, sid)
+        if wait:
+            self._prefill_now([s])
+        else:
+            with self.tr.on_stream():
+                self._write_row(s)
+            s.active = False
+            self._prefill_waiting.append((s, s.tsp))
+            self._pump_prefills()
+        return s.sid
+
+    def add_streams(self, requests: list[dict]) -> list:
+        """Admits several requests at once (dicts of add_stream's arguments, without `wait`): their prompts are
+        packed into ONE prefill (all rows of all prompts through each GEMM together — the reference's scheduler packs
+        the prompts that arrive within its collection window the same way, P/engine/scheduler.py:31-56), which costs
+        about half of prefilling them one after the other.  Returns, per request and in order, the stream id or the
+        exception (NoCapacity / ValueError) that add_stream would have raised; the ids a stream then produces do not
+        depend on what it was packed with."""
+        out, fresh = [], []
+        for r in requests:
+            try:
+                s = self._reserve(r["prompt_embeds"], r["text_adds"], r["max_frames"], r.get("talker_sampling"),
+                                  r.get("predictor_sampling"), r.get("sid"))
+                fresh.append(s)
+                out.append(s.sid)
+            except (NoCapacity, ValueError) as e:
+                out.append(e)
+        if fresh:
+            self._prefill_now(fresh)
+        return out
+
+    def _reserve(self, prompt_embeds, text_adds, max_frames, talker_sampling, predictor_sampling, sid) -> Stream:
+        """Checks the request, takes a row and the KV blocks of the stream's whole lifetime."""
         tsp = talker_sampling or SamplingParams(temperature=1.0, max_tokens=1)
         psp = predictor_sampling or SamplingParams(temperature=0.9, max_tokens=17)
         for sp in (tsp, psp):
@@ -140,50 +170,69 @@ class FrameEngine:
         if prompt_embeds.shape[-1] != self.H or text_adds.dim() != 2 or text_adds.shape[-1] != self.H or text_adds.shape[0] < 1:
             raise ValueError(f"prompt_embeds [L,{self.H}] and text_adds [F>=1,{self.H}] expected, got "
                              f"{tuple(prompt_embeds.shape)} and {tuple(text_adds.shape)}")
-        seq = Sequence([], input_embeds=prompt_embeds.reshape(1, L, -1), sampling_params=tsp, request_id=sid)
+        if L > self.tr.max_rows:
+            raise ValueError(f"prompt of {L} tokens: the engine was built for at most {self.tr.max_rows} prompt rows per step")
+        row = next((i for i, s in enumerate(self.rows) if s is None), None)
+        if row is None:
+            raise NoCapacity("all stream rows are taken")
         bm = self.talker.scheduler.block_manager
         need = (total + 255) // 256
         if len(bm.free_block_ids) < need:
             raise NoCapacity(f"{need} KV blocks needed, {len(bm.free_block_ids)} free")
+        sid = sid or f"stream-{self._next_sid}"
+        self._next_sid += 1
+        seq = Sequence([], input_embeds=prompt_embeds.reshape(1, L, -1), sampling_params=tsp, request_id=sid)
         seq.block_table = [bm._take() for _ in range(need)]
-        with self.tr.on_stream():
-            if wait:
-                toks, hidden = self.tr._run([seq], True)      # prefill (eager path of the runner)
-                seq.append_token(toks[0], None)
-            F = min(text_adds.shape[0], self.max_text_frames)
-            self.text_add[row, :F].copy_(text_adds[:F].to(self.device, torch.float32), non_blocking=True)
-            if F < self.max_text_frames:
-                self.text_add[row, F:] = text_adds[F - 1].to(self.device, torch.float32)
-            if wait:
-                self.cur_hidden[row].copy_(hidden[0])
-                self.cur_token[row] = toks[0]
-            self.frame_idx[row] = 0
-            self.ctx_limit[row] = total - 1                # the talker step that closes frame max_frames - 1
-            self.temps_t[row] = tsp.temperature
-            self.temps_p[row] = psp.temperature
-            self.greedy_t[row] = 0 if tsp.do_sample else 1
-            self.greedy_p[row] = 0 if psp.do_sample else 1
-            # talker decode metadata for the token that WILL be fed next: prepare_decode_talker semantics
-            st, mb = self.tr.dstage, self.tr.max_blocks_per_seq
-            n = L + 1                                      # len(seq) once the prefill's first code is appended
-            st.h("positions")[row] = n - 1                 # advance_decode adds 1 before the first decode
-            st.h("ctx")[row] = n - 1
-            st.h("slots")[row] = -1
-            tab = st.h("tables")[:self.max_streams * mb].view(self.max_streams, mb)
-            tab[row].fill_(0)
-            tab[row, :need] = torch.tensor(seq.block_table, dtype=torch.int32)
-            if wait:
-                self._sync_row_to_device(row)
-        s = Stream(sid, row, seq, F, max_frames)
+        s = Stream(sid, row, seq, min(text_adds.shape[0], self.max_text_frames), max_frames)
+        s.tsp, s.psp, s.text_adds, s.prompt_len, s.need = tsp, psp, text_adds, L, need
         self.rows[row] = s
         self.streams[sid] = s
-        if wait:
-            s.first_token = toks[0]
-        else:
-            s.active = False
-            self._prefill_waiting.append((s, tsp))
-            self._pump_prefills()
-        return sid
+        return s
+
+    def _write_row(self, s: Stream):
+        """The row's per-stream state (on the engine's stream): text additions, sampling, frame counter, the talker's
+        decode metadata for the token that WILL be fed next."""
+        row, F, text_adds = s.row, s.n_text, s.text_adds
+        self.text_add[row, :F].copy_(text_adds[:F].to(self.device, torch.float32), non_blocking=True)
+        if F < self.max_text_frames:
+            self.text_add[row, F:] = text_adds[F - 1].to(self.device, torch.float32)
+        s.text_adds = None
+        self.frame_idx[row] = 0
+        self.ctx_limit[row] = s.prompt_len + s.max_frames      # the talker step that closes frame max_frames - 1
+        self.temps_t[row] = s.tsp.temperature
+        self.temps_p[row] = s.psp.temperature
+        self.greedy_t[row] = 0 if s.tsp.do_sample else 1
+        self.greedy_p[row] = 0 if s.psp.do_sample else 1
+        # prepare_decode_talker semantics for a sequence of prompt + first code
+        st, mb = self.tr.dstage, self.tr.max_blocks_per_seq
+        n = s.prompt_len + 1
+        st.h("positions")[row] = n - 1                     # advance_decode adds 1 before the first decode
+        st.h("ctx")[row] = n - 1
+        st.h("slots")[row] = -1
+        tab = st.h("tables")[:self.max_streams * mb].view(self.max_streams, mb)
+        tab[row].fill_(0)
+        tab[row, :s.need] = torch.tensor(s.seq.block_table, dtype=torch.int32)
+
+    def _prefill_now(self, streams: list[Stream]):
+        """Prefills the prompts of freshly reserved streams between two frames, packed into as few runner steps as the
+        runner's row limit allows, and switches the streams on."""
+        groups, rows = [[]], 0
+        for s in streams:
+            if groups[-1] and rows + s.prompt_len > self.tr.max_rows:
+                groups.append([])
+                rows = 0
+            groups[-1].append(s)
+            rows += s.prompt_len
+        with self.tr.on_stream():
+            for group in groups:
+                toks, hidden = self.tr._run([s.seq for s in group], True)      # eager path of the runner
+                for i, s in enumerate(group):
+                    s.seq.append_token(toks[i], None)
+                    s.first_token = toks[i]
+                    self._write_row(s)
+                    self.cur_hidden[s.row].copy_(hidden[i])
+                    self.cur_token[s.row] = toks[i]
+                    self._sync_row_to_device(s.row)
 
     # ---------------------------------------------------------------- prefill beside the frames
     def _start_prefill(self, s: Stream, tsp: SamplingParams):

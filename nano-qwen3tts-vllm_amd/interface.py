@@ -230,29 +230,41 @@ class Qwen3TTSInterface:
                 fe.remove_stream(rid)
                 budget.pop(rid, None)
             self._fused_cancelled.clear()
-            still_waiting = []
-            for req in self._fused_pending:
-                rid, prompt, text_adds, n, tsp, psp = req
-                if len(fe.streams) >= fe.max_streams:
-                    still_waiting.append(req)
+            # what can be admitted now goes to the engine in ONE call: prompts that arrived together are prefilled
+            # packed (the reference's scheduler does the same with what its collection window gathers).  The batch
+            # leaves the pending list before the engine is awaited: requests that arrive meanwhile are appended behind.
+            room = max(fe.max_streams - len(fe.streams), 0)
+            batch = self._fused_pending[:room]
+            del self._fused_pending[:room]
+            if batch and self._admit_wait and hasattr(fe, "add_streams"):
+                results = await off_loop(fe.add_streams, [dict(prompt_embeds=p_, text_adds=t_, max_frames=n, talker_sampling=tsp,
+                                                                 predictor_sampling=psp, sid=rid)
+                                                            for rid, p_, t_, n, tsp, psp in batch])
+            else:
+                results = []
+                for rid, p_, t_, n, tsp, psp in batch:
+                    try:
+                        results.append(await off_loop(fe.add_stream, p_, t_, max_frames=n, talker_sampling=tsp,
+                                                      predictor_sampling=psp, sid=rid, wait=self._admit_wait))
+                    except (NoCapacity, AssertionError, ValueError) as e:
+                        results.append(e)
+            retry = []
+            for req, r in zip(batch, results):
+                rid = req[0]
+                if not isinstance(r, Exception):
+                    if rid in self._request_queues:
+                        budget[rid] = req[3]
+                    else:                                             # its consumer went away during the prefill
+                        fe.remove_stream(rid)
                     continue
-                try:
-                    await off_loop(fe.add_stream, prompt, text_adds, max_frames=n, talker_sampling=tsp,
-                                   predictor_sampling=psp, sid=rid, wait=self._admit_wait)
-                    budget[rid] = n
+                if isinstance(r, NoCapacity) and fe.streams:         # blocks come back when a running stream ends
+                    retry.append(req)
                     continue
-                except NoCapacity as e:
-                    if fe.streams:                                # blocks come back when a running stream ends
-                        still_waiting.append(req)
-                        continue
-                    reason = e
-                except (AssertionError, ValueError) as e:         # can never be served (too long, unsupported top_k)
-                    reason = e
-                logger.warning(f"[fused_loop] request {rid[:8]} rejected: {reason}")
+                logger.warning(f"[fused_loop] request {rid[:8]} rejected: {r}")     # can never be served
                 q = self._request_queues.get(rid)
                 if q is not None:
                     q.put_nowait(None)
-            self._fused_pending[:] = still_waiting
+            self._fused_pending[:0] = [r for r in retry if r[0] in self._request_queues]
             if not fe.streams:
                 self._fused_wake.clear()
                 if not self._fused_pending:

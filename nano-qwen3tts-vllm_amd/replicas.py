@@ -93,17 +93,27 @@ def replica_main(index: int, device_index: int | None, factory: str, factory_kwa
             elif cmd[0] == _CMD_ADD and running:
                 waiting.append(cmd)
         still = []
-        for cmd in waiting:
-            _, rid, prompt, text_adds, max_frames, tsp, psp = cmd
-            try:
-                engine.add_stream(_to_tensor(prompt), _to_tensor(text_adds), max_frames=max_frames,
-                                  talker_sampling=SamplingParams(**tsp), predictor_sampling=SamplingParams(**psp), sid=rid,
-                                  **admit_kw)
-            except Exception as e:
-                if type(e).__name__ == "NoCapacity" and engine.streams:
-                    still.append(cmd)                  # a row / KV blocks come back when a running stream ends
-                else:
-                    res_q.put((rid, _END, f"rejected: {e}"))
+        room = max(getattr(engine, "max_streams", len(waiting)) - len(engine.streams), 0)
+        batch, later = waiting[:room], waiting[room:]
+        reqs = [dict(prompt_embeds=_to_tensor(c[2]), text_adds=_to_tensor(c[3]), max_frames=c[4],
+                     talker_sampling=SamplingParams(**c[5]), predictor_sampling=SamplingParams(**c[6]), sid=c[1]) for c in batch]
+        if reqs and not admit_kw and hasattr(engine, "add_streams"):
+            results = engine.add_streams(reqs)             # prompts that arrived together: one packed prefill
+        else:
+            results = []
+            for r in reqs:
+                try:
+                    results.append(engine.add_stream(**r, **admit_kw))
+                except Exception as e:
+                    results.append(e)
+        for cmd, r in zip(batch, results):
+            if not isinstance(r, Exception):
+                continue
+            if type(r).__name__ == "NoCapacity" and engine.streams:
+                still.append(cmd)                          # a row / KV blocks come back when a running stream ends
+            else:
+                res_q.put((cmd[1], _END, f"rejected: {r}"))
+        still += later
         waiting[:] = still
         if not engine.streams:
             continue

@@ -35,6 +35,15 @@ class FakeFrameEngine:
         self.streams[sid] = SimpleNamespace(key=key, n=0, limit=min(max_frames, FRAMES))
         return sid
 
+    def add_streams(self, requests):
+        out = []
+        for r in requests:
+            try:
+                out.append(self.add_stream(**r))
+            except (NoCapacity, AssertionError, ValueError) as e:
+                out.append(e)
+        return out
+
     def remove_stream(self, sid):
         self.streams.pop(sid, None)
 

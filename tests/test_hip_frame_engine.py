@@ -334,3 +334,55 @@ def test_burst_steps_without_metadata_arrays_give_the_same_ids(tmp_path, monkeyp
         fe.exit()
     assert torch.equal(res["1"][0], res["0"][0])
     assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
+
+
+def test_prompts_admitted_together_are_prefilled_packed_and_give_the_same_ids(tmp_path):
+    """add_streams: the prompts of several requests go through ONE packed prefill (ragged lengths, one of them
+    longer than a KV block).  Every stream's ids equal a run of that stream admitted alone; a request that can never
+    be served and one that does not fit right now come back as their exceptions, in order, without disturbing the
+    others; prompts that together exceed the runner's row limit (600 + 500 > 1024) are packed in two groups."""
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine, NoCapacity
+    cfg, sd, tw, pw, g = fixture_model("sharp")
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(77)
+    H = cfg["talker_config"]["hidden_size"]
+    prompts = [torch.randn(L, H, generator=gen) * 0.5 for L in (9, 300, 40, 130, 600, 500)]
+    texts = [torch.randn(8, H, generator=gen) * 0.3 for _ in prompts]
+    kw = dict(max_streams=4, max_text_frames=16, talker_weights=tw, predictor_weights=pw, num_kvcache_blocks=12,
+              max_num_batched_tokens=1024, codec_eos=None)
+    sp = dict(talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+
+    def solo(i):
+        fe = FrameEngine(str(tmp_path), **kw)
+        fe.add_stream(prompts[i], texts[i], max_frames=5, **sp)
+        out = fe.run_frames(5)[:, 0].tolist()
+        fe.exit()
+        return out
+
+    want = [solo(i) for i in range(6)]
+    fe = FrameEngine(str(tmp_path), **kw)
+    free0 = len(fe.talker.scheduler.block_manager.free_block_ids)
+    reqs = [dict(prompt_embeds=prompts[0], text_adds=texts[0], max_frames=5, sid="a", **sp),
+            dict(prompt_embeds=torch.zeros(1000, H), text_adds=texts[0], max_frames=100, sid="too long", **sp),
+            dict(prompt_embeds=prompts[1], text_adds=texts[1], max_frames=5, sid="b", **sp),
+            dict(prompt_embeds=prompts[2], text_adds=texts[2], max_frames=5, sid="c", **sp),
+            dict(prompt_embeds=prompts[3], text_adds=texts[3], max_frames=5, sid="d", **sp),
+            dict(prompt_embeds=prompts[0], text_adds=texts[0], max_frames=5, sid="no row left", **sp)]
+    res = fe.add_streams(reqs)
+    assert res[0] == "a" and res[2:5] == ["b", "c", "d"]
+    assert isinstance(res[1], ValueError) and isinstance(res[5], NoCapacity)
+    assert sorted(fe.streams) == ["a", "b", "c", "d"]
+    rows = {sid: fe.streams[sid].row for sid in "abcd"}
+    out = fe.run_frames(5)
+    for i, sid in enumerate("abcd"):
+        assert out[:, rows[sid]].tolist() == want[i], sid
+    for sid in "abcd":
+        fe.remove_stream(sid)
+    assert len(fe.talker.scheduler.block_manager.free_block_ids) == free0
+    # two prompts that do not fit one runner step together
+    res = fe.add_streams([dict(prompt_embeds=prompts[i], text_adds=texts[i], max_frames=5, sid=f"long{i}", **sp) for i in (4, 5)])
+    assert res == ["long4", "long5"]
+    rows = {sid: fe.streams[sid].row for sid in res}
+    out = fe.run_frames(5)
+    assert out[:, rows["long4"]].tolist() == want[4] and out[:, rows["long5"]].tolist() == want[5]
+    fe.exit()
