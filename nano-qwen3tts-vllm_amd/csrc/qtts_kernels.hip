@@ -310,6 +310,38 @@ struct LinTail {
 // of row r, lane (g, r + 8) the ODD k-steps of the same row, and a row rotate hands each its partner's result.  Half
 // the activation requests and half the normalisation arithmetic per lane; the sum of squares is added up in the same
 // order in both forms (even k-steps, odd k-steps, then their sum), so both return the same bits.
+// Sum of the waves' partial results kept in LDS, base[w * stride] for w = 0 .. nw-1, added in that order.  For the
+// wave counts the launches use, every read is issued before the first addition: a loop over a run-time count
+// compiles to a chain of dependent reads, each waiting out the LDS latency (about 0.3 us for eight waves on the
+// critical path of every GEMM launch).  The order of the additions, and with it every bit, is the loop's.
+// BATCH: reads in flight at a time (a kernel short of registers takes the reads in two batches).
+template <typename T, int NWC, int BATCH = NWC>
+__device__ __forceinline__ T sum_partials_fixed(const T *base, int stride) {
+    static_assert(NWC % BATCH == 0, "whole batches");
+    T acc;
+#pragma unroll
+    for (int b = 0; b < NWC; b += BATCH) {
+        T part[BATCH];
+#pragma unroll
+        for (int w = 0; w < BATCH; ++w) part[w] = base[(b + w) * stride];
+#pragma unroll
+        for (int w = 0; w < BATCH; ++w) acc = (b + w == 0) ? part[0] : acc + part[w];
+    }
+    return acc;
+}
+template <typename T>
+__device__ __forceinline__ T sum_partials(const T *base, int stride, int nw) {
+    switch (nw) {
+    case 8: return sum_partials_fixed<T, 8>(base, stride);
+    case 4: return sum_partials_fixed<T, 4>(base, stride);
+    case 2: return sum_partials_fixed<T, 2>(base, stride);
+    default: break;
+    }
+    T acc = base[0];
+    for (int w = 1; w < nw; ++w) acc += base[w * stride];
+    return acc;
+}
+
 template <int KSW, int PRO, bool DB, int EPI, bool SUB = false, bool W8 = false, bool H8 = false>
 __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uint4 *wp, const int64_t *ids, int ldx, int K,
                                                       int N, int M, int tiles_per_wg, int dbg, int id_rows,
@@ -473,8 +505,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         ss += __shfl_xor(ss, 32);
         if (g == 0) normred[wave * 16 + r] = ss;
         __syncthreads();
-        float tot = 0.f;
-        for (int w = 0; w < NW; ++w) tot += normred[w * 16 + r];
+        const float tot = sum_partials(normred + r, 16, NW);
         const float rstd = 1.0f / sqrtf(tot / (float)p.K + p.eps);
 #pragma unroll
         for (int i = 0; i < KSW; ++i) {
@@ -508,14 +539,17 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     auto tile_body = [&](const int cur, const int t, const int it) {
         // residual / bias words of this tile are requested up front by the wave that will need them, so the
         // epilogue does not start another memory round trip after the reduction
+        // The wave that finishes a tile (cross-wave sum, epilogue, store) alternates between waves 0 and 1: the
+        // finishing of tile t then overlaps the multiplications of tile t + 1 instead of preceding them in one wave.
+        const bool finisher = wave == (NW > 1 ? (it & 1) : 0);
         uint2 resw = make_uint2(0, 0), biasw = make_uint2(0, 0);
-        if (EPI == 0 && wave == 0 && orow) {
+        if (EPI == 0 && finisher && orow) {
             if (p.res && mvalid) resw = *reinterpret_cast<const uint2 *>(p.res + rrow + 16 * t + 4 * g);
             if (p.bias) biasw = *reinterpret_cast<const uint2 *>(p.bias + 16 * t + 4 * g);
         }
         // fp8 weights: the rows' power-of-two scales, requested up front for the same reason
         float4_t wsc = {1.f, 1.f, 1.f, 1.f}, wsc_up = {1.f, 1.f, 1.f, 1.f};
-        if (W8 && wave == 0) {
+        if (W8 && finisher) {
             wsc = *reinterpret_cast<const float4_t *>(tl.wscale + 16 * t + 4 * g);
             if (EPI == 1 && g < 2) wsc_up = *reinterpret_cast<const float4_t *>(tl.wscale + 16 * t + 8 + 4 * g);
         }
@@ -549,15 +583,13 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         QTTS_TRACE(1);
         __syncthreads();
         QTTS_TRACE(2);
-        if (wave == 0) {
-            float4_t sum = red[lane];
-            for (int w = 1; w < NW; ++w) sum += red[w * 64 + lane];
+        if (finisher) {
+            float4_t sum = sum_partials(red + lane, 64, NW);
             // fp8 weights: the row's power-of-two scale, exact in fp32 (same result as bf16 weights q * scale)
             if (W8) sum *= wsc;
             if (EPI == 1) {
                 if (g < 2) {                              // lanes 0..31 hold gate rows; the up rows sit 32 lanes on
-                    float4_t ups = red[lane + 32];
-                    for (int w = 1; w < NW; ++w) ups += red[w * 64 + lane + 32];
+                    float4_t ups = sum_partials(red + lane + 32, 64, NW);
                     if (W8) ups *= wsc_up;
                     if (mvalid) {
                         float v[4];
@@ -726,11 +758,19 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
         __syncthreads();
         QTTS_RTRACE(2 + 2 * it);
         if (wave >= TM) return;
-        // wave i finishes row tile i of this weight tile
+        // wave i finishes row tile i of this weight tile (all eight waves' partial sums, added in wave order)
         const float4_t *mine = red + wave * 64;
         const int m = (by * TM + wave) * 16 + r;
-        float4_t sum = mine[lane];
-        for (int w = 1; w < NW; ++w) sum += mine[w * TM * 64 + lane];
+        // (the SwiGLU form with four row tiles has no registers to spare: it keeps the one-read-at-a-time loop)
+        constexpr bool TIGHT = EPI == 1 && TM > 2 && KSW >= 8;
+        constexpr int RB = (TM > 2 && KSW >= 8) ? 4 : 8;
+        float4_t sum;
+        if constexpr (TIGHT) {
+            sum = mine[lane];
+            for (int w = 1; w < NW; ++w) sum += mine[w * TM * 64 + lane];
+        } else {
+            sum = sum_partials_fixed<float4_t, 8, RB>(mine + lane, TM * 64);
+        }
         if (W8) sum *= wsc;                                // exact: powers of two
         if (EPI == 2) {
             if (m < M)
@@ -739,8 +779,13 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
         }
         if (EPI == 1) {
             if (g < 2) {                                  // lanes 0..31 hold gate rows; the up rows sit 32 lanes on
-                float4_t ups = mine[lane + 32];
-                for (int w = 1; w < NW; ++w) ups += mine[w * TM * 64 + lane + 32];
+                float4_t ups;
+                if constexpr (TIGHT) {
+                    ups = mine[lane + 32];
+                    for (int w = 1; w < NW; ++w) ups += mine[w * TM * 64 + lane + 32];
+                } else {
+                    ups = sum_partials_fixed<float4_t, 8, RB>(mine + lane + 32, TM * 64);
+                }
                 if (W8) ups *= wsc_up;
                 if (m < M) {
                     float v[4];

@@ -9,7 +9,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "nano-qwen3tts-vllm_amd", "csrc", "libqtts_hip_tuning.so")
+# QTTS_TUNING_LIB: another -DQTTS_TUNING build of the same source (an experiment compiled with extra -D flags)
+LIB = os.environ.get("QTTS_TUNING_LIB") or os.path.join(ROOT, "nano-qwen3tts-vllm_amd", "csrc", "libqtts_hip_tuning.so")
 if not os.path.exists(LIB):
     raise SystemExit(f"{LIB} is missing: build it with `python nano-qwen3tts-vllm_amd/csrc/build.py --tuning`")
 os.environ["QTTS_LIB"] = LIB
