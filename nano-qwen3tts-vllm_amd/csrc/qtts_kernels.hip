@@ -585,11 +585,18 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         QTTS_TRACE(2);
         if (finisher) {
             float4_t sum = sum_partials(red + lane, 64, NW);
+            // SwiGLU: lanes 0..31 hold gate rows, the up rows of the same outputs sit 32 lanes on - their sums are
+            // what those lanes have just added up (same partials, same order), so they are fetched from there with
+            // a lane permute instead of a second pass over the partials
+            float4_t ups = sum;
+            if (EPI == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ups[j] = __shfl(sum[j], (lane + 32) & 63);
+            }
             // fp8 weights: the row's power-of-two scale, exact in fp32 (same result as bf16 weights q * scale)
             if (W8) sum *= wsc;
             if (EPI == 1) {
-                if (g < 2) {                              // lanes 0..31 hold gate rows; the up rows sit 32 lanes on
-                    float4_t ups = sum_partials(red + lane + 32, 64, NW);
+                if (g < 2) {
                     if (W8) ups *= wsc_up;
                     if (mvalid) {
                         float v[4];
@@ -761,15 +768,14 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
         // wave i finishes row tile i of this weight tile (all eight waves' partial sums, added in wave order)
         const float4_t *mine = red + wave * 64;
         const int m = (by * TM + wave) * 16 + r;
-        // (the SwiGLU form with four row tiles has no registers to spare: it keeps the one-read-at-a-time loop)
-        constexpr bool TIGHT = EPI == 1 && TM > 2 && KSW >= 8;
+        // (four row tiles of activations leave few registers: the reads go out in two batches of four)
         constexpr int RB = (TM > 2 && KSW >= 8) ? 4 : 8;
-        float4_t sum;
-        if constexpr (TIGHT) {
-            sum = mine[lane];
-            for (int w = 1; w < NW; ++w) sum += mine[w * TM * 64 + lane];
-        } else {
-            sum = sum_partials_fixed<float4_t, 8, RB>(mine + lane, TM * 64);
+        float4_t sum = sum_partials_fixed<float4_t, 8, RB>(mine + lane, TM * 64);
+        // SwiGLU: the up rows' sums are what the lanes 32 on have just added up (fetched with a lane permute)
+        float4_t ups = sum;
+        if (EPI == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ups[j] = __shfl(sum[j], (lane + 32) & 63);
         }
         if (W8) sum *= wsc;                                // exact: powers of two
         if (EPI == 2) {
@@ -778,14 +784,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
             return;
         }
         if (EPI == 1) {
-            if (g < 2) {                                  // lanes 0..31 hold gate rows; the up rows sit 32 lanes on
-                float4_t ups;
-                if constexpr (TIGHT) {
-                    ups = mine[lane + 32];
-                    for (int w = 1; w < NW; ++w) ups += mine[w * TM * 64 + lane + 32];
-                } else {
-                    ups = sum_partials_fixed<float4_t, 8, RB>(mine + lane + 32, TM * 64);
-                }
+            if (g < 2) {
                 if (W8) ups *= wsc_up;
                 if (m < M) {
                     float v[4];
@@ -2012,13 +2011,35 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
         const int h = e >> 7, d = e & 127;
         const int hq = kvh * G + h;
         const size_t p0 = ((size_t)row * Hq + hq) * a_nsplit;
-        float M = -INFINITY;
-        for (int s = 0; s < nact; ++s) M = fmaxf(M, ld_agent(p.part_ml + (p0 + s) * 2));
-        float L = 0.f, o = 0.f;
-        for (int s = 0; s < nact; ++s) {
-            const float wgt = __expf(ld_agent(p.part_ml + (p0 + s) * 2) - M);
-            L += ld_agent(p.part_ml + (p0 + s) * 2 + 1) * wgt;
-            o += ld_agent(p.part_o + (p0 + s) * 128 + d) * wgt;
+        float M = -INFINITY, L = 0.f, o = 0.f;
+        constexpr int MERGE_MAX = 8;                    // splits merged with all their partials requested at once
+        if (nact <= MERGE_MAX) {
+            // Every partial of the row in ONE batch of requests (a split past the row's last one re-reads that last
+            // one and is left out of the sums): these loads go to the level all XCDs share, about a microsecond
+            // each way, and a loop over the splits pays that once per split and again for the second pass.
+            float pm[MERGE_MAX], pl[MERGE_MAX], po[MERGE_MAX];
+#pragma unroll
+            for (int s = 0; s < MERGE_MAX; ++s) {
+                const int si = s < nact ? s : nact - 1;
+                pm[s] = ld_agent(p.part_ml + (p0 + si) * 2);
+                pl[s] = ld_agent(p.part_ml + (p0 + si) * 2 + 1);
+                po[s] = ld_agent(p.part_o + (p0 + si) * 128 + d);
+            }
+#pragma unroll
+            for (int s = 0; s < MERGE_MAX; ++s) M = fmaxf(M, pm[s]);          // (a repeated value changes nothing)
+#pragma unroll
+            for (int s = 0; s < MERGE_MAX; ++s) {
+                const float wgt = __expf(pm[s] - M);
+                L = s < nact ? L + pl[s] * wgt : L;
+                o = s < nact ? o + po[s] * wgt : o;
+            }
+        } else {
+            for (int s = 0; s < nact; ++s) M = fmaxf(M, ld_agent(p.part_ml + (p0 + s) * 2));
+            for (int s = 0; s < nact; ++s) {
+                const float wgt = __expf(ld_agent(p.part_ml + (p0 + s) * 2) - M);
+                L += ld_agent(p.part_ml + (p0 + s) * 2 + 1) * wgt;
+                o += ld_agent(p.part_o + (p0 + s) * 128 + d) * wgt;
+            }
         }
         p.out[(size_t)row * p.ldo + (size_t)hq * 128 + d] = f2bf(o / L);
     }
