@@ -261,6 +261,9 @@ struct LinArgs {
     const bf16_t *next_nw = nullptr; bf16_t *next_xn = nullptr; int ldnn = 0;   // K-split prompt GEMM only: also RMSNorm(out) * next_nw
     const float *wscale = nullptr;   // non-null: wp holds fp8 (e4m3) weights, two k-steps per 16-byte fragment; scale per packed row
     const int64_t *res_ids = nullptr; int res_id_rows = 0;   // non-null: residual row m = res[res_ids[m]] (decode GEMM only)
+    // prompt GEMMs between the kernels of one layer: x / the SwiGLU output / the fused norm's output in fragment
+    // order (act_index) instead of row-major
+    int xpacked = 0, opks = 0, nnpks = 0;
     int dbg;      // bit0: tuning experiment (every tile reads weight tile 0); bit3: `ids` select the residual rows, not the
                   // x rows; bits 4-5: log2 of the workgroups per tile; bits 8+: row-tile count of a prefill launch
 };
@@ -310,6 +313,16 @@ struct LinTail {
 // of row r, lane (g, r + 8) the ODD k-steps of the same row, and a row rotate hands each its partner's result.  Half
 // the activation requests and half the normalisation arithmetic per lane; the sum of squares is added up in the same
 // order in both forms (even k-steps, odd k-steps, then their sum), so both return the same bits.
+// Where element (row m, column k) of an activation matrix lives.  Row-major (pks == 0): m * ld + k.  Fragment order
+// (pks = K / 32 > 0): [row tile m / 16][k-step k / 32][lane = 16 * ((k % 32) / 8) + m % 16][k % 8] - the order in which
+// the MFMA B operand of a 16-row tile is consumed, so that the prompt GEMM reads one contiguous KiB per request (as
+// it does for the packed weights) instead of sixty-four bytes from each of sixteen rows.  Used between the kernels of
+// a prompt's layer only (normalised rows, attention output, SwiGLU output); buffers hold whole 16-row tiles.
+__device__ __forceinline__ size_t act_index(int m, int k, int ld, int pks) {
+    if (pks == 0) return (size_t)m * ld + k;
+    return ((((size_t)(m >> 4) * pks + (k >> 5)) * 64) + (((k & 31) >> 3) << 4) + (m & 15)) * 8 + (k & 7);
+}
+
 // Sum of the waves' partial results kept in LDS, base[w * stride] for w = 0 .. nw-1, added in that order.  For the
 // wave counts the launches use, every read is issued before the first addition: a loop over a run-time count
 // compiles to a chain of dependent reads, each waiting out the LDS latency (about 0.3 us for eight waves on the
@@ -666,6 +679,9 @@ struct RowsArgs {
     float *part; int mpad;       // EPI 2: part[kpart][mpad][N]
     int rgroups, KS;             // row groups of TM tiles; k-steps of a whole packed weight tile
     const float *wscale;         // fp8 weights: scale per packed weight row
+    int xpacked;                 // x is in fragment order (act_index): whole 16-row tiles
+    int opks;                    // EPI 1: > 0 = `out` in fragment order with this many k-steps (the next GEMM's K / 32)
+    int xnpks;                   // K-split: > 0 = the fused norm's output in fragment order
 #ifdef QTTS_TUNING
     long long *trace;            // 32 timestamps per workgroup
 #endif
@@ -703,9 +719,14 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mi = (by * TM + i) * 16 + r;
-        const bf16_t *xp = x + (size_t)(mi < M ? mi : 0) * ldx + 32 * ks0 + 8 * g;
+        // row-major: 16 rows x 64 bytes per request; fragment order: one contiguous KiB per request (a row tile past
+        // the last one re-reads the last: never stored)
+        const int mtl = (M + 15) >> 4, rt = min(by * TM + i, mtl - 1);
+        const bf16_t *xp = p.xpacked ? x + (((size_t)rt * p.KS + ks0) * 64 + lane) * 8
+                                     : x + (size_t)(mi < M ? mi : 0) * ldx + 32 * ks0 + 8 * g;
+        const int kstep = p.xpacked ? 512 : 32;
 #pragma unroll
-        for (int k = 0; k < KSW; ++k) xb[i][k].u = *reinterpret_cast<const uint4 *>(xp + 32 * k);
+        for (int k = 0; k < KSW; ++k) xb[i][k].u = *reinterpret_cast<const uint4 *>(xp + (size_t)kstep * k);
     }
     // Two weight tiles are in flight: a fragment register is refilled with the tile after next as soon as its
     // multiplications are issued, so the loads of tile t+2 go out while tile t is still being multiplied.
@@ -794,7 +815,7 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
                         const float sv = rbf(silu_f(gv));
                         v[j] = sv * rbf(ups[j]);
                     }
-                    *reinterpret_cast<uint2 *>(p.out + (size_t)m * p.ldo + 8 * t + 4 * g) =
+                    *reinterpret_cast<uint2 *>(p.out + act_index(m, 8 * t + 4 * g, p.ldo, p.opks)) =
                         make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
                 }
             }
@@ -867,7 +888,8 @@ __global__ __launch_bounds__(256) void linear_parts_kernel(const float *part, in
 // consumes it (the arithmetic and summation order of rmsnorm_kernel): saves the norm's own launch.  N % 8 == 0.
 __global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *part, int kparts, int mpad, int N,
                                                                 const bf16_t *bias, const bf16_t *res, int ldr, bf16_t *out,
-                                                                int ldo, const bf16_t *nw, float eps, bf16_t *xn, int ldxn) {
+                                                                int ldo, const bf16_t *nw, float eps, bf16_t *xn, int ldxn,
+                                                                int xnpks) {
     __shared__ float red[4];
     const int m = blockIdx.x;
     bf16_t *orow = out + (size_t)m * ldo;
@@ -907,7 +929,7 @@ __global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *par
         wv.u = *reinterpret_cast<const uint4 *>(nw + n);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.h[j] = f2bf(rbf(bf2f(f.h[j]) * rstd) * bf2f(wv.h[j]));
-        *reinterpret_cast<uint4 *>(xn + (size_t)m * ldxn + n) = o.u;
+        *reinterpret_cast<uint4 *>(xn + act_index(m, n, ldxn, xnpks)) = o.u;
     }
 }
 
@@ -983,6 +1005,25 @@ static bool linear_rows_is_ksplit(int M, int N, int K, size_t scratch_bytes) {
 
 // Prompt GEMM (more than one 16-row tile, plain activations).  Returns false when the shape is not covered and the
 // caller should take the single-tile path.
+// Whether launch_linear_rows takes this shape (the decision a caller needs before it lays activations out in fragment
+// order, which only that kernel reads).
+static bool linear_rows_covers(int M, int N, int K, bool silu_pairs, bool has_bias, bool has_scratch, size_t scratch_bytes) {
+    if (M <= g_rows_min || (g_dbg_linear & 2) || K % 32 != 0 || N % 16 != 0) return false;
+    const int KS = K / 32;
+    if (KS % 8 != 0) return false;
+    int ksw = KS / 8, kparts = 1;
+    if (ksw > 12) {
+        if (ksw % 8 != 0 || silu_pairs) return false;
+        kparts = ksw / 8;
+        ksw = 8;
+        if (!has_scratch || scratch_bytes < (size_t)kparts * M * N * sizeof(float)) return false;
+    }
+    if (ksw != 4 && ksw != 8 && ksw != 12) return false;
+    if (ksw == 12 && silu_pairs) return false;
+    if (has_bias && kparts == 1) return false;
+    return true;
+}
+
 static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch, size_t scratch_bytes, hipStream_t s) {
     const int KS = a.K / 32;
     if (KS % 8 != 0) return false;
@@ -1005,6 +1046,7 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     r.trace = g_trace;
 #endif
     r.wscale = a.wscale;
+    r.xpacked = a.xpacked; r.opks = a.opks; r.xnpks = a.nnpks;
     const int ntiles = a.N / 16;
     // One round of workgroups (a CU holds one, an XCD 32): workgroup i runs on XCD i % 8 and the launch is laid out
     // in groups of 8 column blocks x all row groups (x K parts), so the groups of 8 that fit one round are
@@ -1030,7 +1072,7 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
         const long quads = (long)a.M * (a.N / 4);
         if (a.next_nw)
             hipLaunchKernelGGL(linear_parts_norm_kernel, dim3(a.M), dim3(256), 0, s, scratch, kparts, a.M, a.N, a.bias, a.res,
-                               a.ldr, a.out, a.ldo, a.next_nw, a.eps, a.next_xn, a.ldnn);
+                               a.ldr, a.out, a.ldo, a.next_nw, a.eps, a.next_xn, a.ldnn, a.nnpks);
         else
             hipLaunchKernelGGL(linear_parts_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, scratch, kparts, a.M,
                                a.M, a.N, a.bias, a.res, a.ldr, a.out, a.ldo);
@@ -1056,6 +1098,7 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
         QLAUNCH();
         return QTTS_OK;
     }
+    if (a.xpacked || a.opks || a.nnpks) QFAIL(QTTS_ESTATE, "linear: activations in fragment order but the prompt GEMM does not take M=%d N=%d K=%d", a.M, a.N, a.K);
     QCHECK(!a.next_nw, "linear: the fused norm of the result exists for the K-split prompt GEMM only");
     const int KS = a.K / 32;
     static const int ksws[] = {1, 2, 4, 6, 8, 12, 24};
@@ -1209,7 +1252,7 @@ extern "C" int qtts_linear_swiglu_fp8(const void *x, int ldx, const void *w_gate
 
 // ------------------------------------------------------------------ rmsnorm (stand-alone)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t *__restrict__ x, int ldx, const bf16_t *__restrict__ w,
-                                                      float eps, bf16_t *__restrict__ y, int ldy, int H) {
+                                                      float eps, bf16_t *__restrict__ y, int ldy, int H, int ypks) {
     __shared__ float red[4];
     const int row = blockIdx.x;
     const bf16_t *xr = x + (size_t)row * ldx;
@@ -1234,19 +1277,26 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t *__restrict__
         wv.u = *reinterpret_cast<const uint4 *>(w + i);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.h[j] = f2bf(rbf(bf2f(f.h[j]) * rstd) * bf2f(wv.h[j]));
-        *reinterpret_cast<uint4 *>(y + (size_t)row * ldy + i) = o.u;
+        *reinterpret_cast<uint4 *>(y + act_index(row, i, ldy, ypks)) = o.u;
     }
+}
+
+// ypks > 0: y in fragment order (act_index) for a prompt GEMM that reads it so
+static int rmsnorm_impl(const void *x, int ldx, const void *w, float eps, void *y, int ldy, int M, int H, int ypks,
+                        qtts_stream_t stream) {
+    QCHECK(x && w && y, "rmsnorm: null pointer");
+    QCHECK(M > 0 && H > 0 && H % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= H && ldy >= H,
+           "rmsnorm: bad shape M=%d H=%d ldx=%d ldy=%d", M, H, ldx, ldy);
+    QCHECK(ypks == 0 || ypks * 32 == H, "rmsnorm: fragment-order output needs H = 32 * k-steps");
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, ldx,
+                       (const bf16_t *)w, eps, (bf16_t *)y, ldy, H, ypks);
+    QLAUNCH();
+    return QTTS_OK;
 }
 
 extern "C" int qtts_rmsnorm(const void *x, int ldx, const void *w, float eps, void *y, int ldy, int M, int H,
                             qtts_stream_t stream) {
-    QCHECK(x && w && y, "rmsnorm: null pointer");
-    QCHECK(M > 0 && H > 0 && H % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= H && ldy >= H,
-           "rmsnorm: bad shape M=%d H=%d ldx=%d ldy=%d", M, H, ldx, ldy);
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, ldx,
-                       (const bf16_t *)w, eps, (bf16_t *)y, ldy, H);
-    QLAUNCH();
-    return QTTS_OK;
+    return rmsnorm_impl(x, ldx, w, eps, y, ldy, M, H, 0, stream);
 }
 
 // ------------------------------------------------------------------ q/k norm + RoPE + KV store
@@ -1338,7 +1388,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(
     const bf16_t *__restrict__ q, int ldq, const bf16_t *__restrict__ kc, const bf16_t *__restrict__ vc,
     const int32_t *__restrict__ block_tables, int max_blocks, const int32_t *__restrict__ row_seq,
     const int32_t *__restrict__ context_lens, float scale, bf16_t *__restrict__ out, int ldo, int Hkv,
-    float *__restrict__ part_o, float *__restrict__ part_ml, int nsplit) {
+    float *__restrict__ part_o, float *__restrict__ part_ml, int nsplit, int opks) {
     __shared__ float sm_acc[16][G][128];
     __shared__ float sm_m[16][G];
     __shared__ float sm_l[16][G];
@@ -1348,7 +1398,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(
     const int t0 = split * ATT_SPLIT;
     if (ctx <= 0) {
         if (split == 0 && nsplit == 1)
-            for (int e = threadIdx.x; e < G * 128; e += 256) out[(size_t)row * ldo + (size_t)kvh * G * 128 + e] = 0;
+            for (int e = threadIdx.x; e < G * 128; e += 256) out[act_index(row, kvh * G * 128 + e, ldo, opks)] = 0;
         return;
     }
     if (t0 >= ctx) return;
@@ -1434,7 +1484,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(
         }
         const int hq = kvh * G + h;
         if (nsplit == 1) {
-            out[(size_t)row * ldo + (size_t)hq * 128 + d] = f2bf(o / L);
+            out[act_index(row, hq * 128 + d, ldo, opks)] = f2bf(o / L);
         } else {
             const size_t pi = ((size_t)row * Hq + hq) * nsplit + split;
             part_o[pi * 128 + d] = o;
@@ -1450,11 +1500,11 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float *__restri
                                                            const float *__restrict__ part_ml,
                                                            const int32_t *__restrict__ context_lens,
                                                            bf16_t *__restrict__ out, int ldo, int Hq, int nsplit,
-                                                           int split_tokens) {
+                                                           int split_tokens, int opks) {
     const int row = blockIdx.x, hq = blockIdx.y, d = threadIdx.x;
     const int ctx = context_lens[row];
     if (ctx <= 0) {
-        out[(size_t)row * ldo + (size_t)hq * 128 + d] = 0;
+        out[act_index(row, hq * 128 + d, ldo, opks)] = 0;
         return;
     }
     const int ns = (ctx + split_tokens - 1) / split_tokens;
@@ -1467,7 +1517,7 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float *__restri
         L += part_ml[(p0 + s) * 2 + 1] * wgt;
         o += part_o[(p0 + s) * 128 + d] * wgt;
     }
-    out[(size_t)row * ldo + (size_t)hq * 128 + d] = f2bf(o / L);
+    out[act_index(row, hq * 128 + d, ldo, opks)] = f2bf(o / L);
 }
 
 // ------------------------------------------------------------------ prompt attention on MFMA
@@ -1494,7 +1544,7 @@ template <int G>
 __global__ __launch_bounds__(512) void prefill_attn_mfma_kernel(
     const bf16_t *__restrict__ q, int ldq, const bf16_t *__restrict__ kc, const bf16_t *__restrict__ vc,
     const int32_t *__restrict__ block_tables, int max_blocks, const int32_t *__restrict__ row_seq,
-    const int32_t *__restrict__ context_lens, float scale, bf16_t *__restrict__ out, int ldo, int N, int Hkv) {
+    const int32_t *__restrict__ context_lens, float scale, bf16_t *__restrict__ out, int ldo, int N, int Hkv, int opks) {
     constexpr int NTG = PA_NTG(G);
     constexpr float NEG = -1e30f;
     extern __shared__ unsigned char pa_smem[];
@@ -1658,7 +1708,7 @@ __global__ __launch_bounds__(512) void prefill_attn_mfma_kernel(
             acc += po[dt * 64 + lane] * wk[k];
         }
         if (rvalid)
-            *reinterpret_cast<uint2 *>(out + (size_t)m * ldo + (size_t)hq * 128 + 16 * dt + 4 * g) =
+            *reinterpret_cast<uint2 *>(out + act_index(m, hq * 128 + 16 * dt + 4 * g, ldo, opks)) =
                 make_uint2(pack2(acc[0] * inv, acc[1] * inv), pack2(acc[2] * inv, acc[3] * inv));
     }
 }
@@ -1671,10 +1721,11 @@ extern "C" size_t qtts_attn_workspace_bytes(int N, int Hq, int max_context) {
     return (size_t)N * Hq * ns * (128 + 2) * sizeof(float) + 256;
 }
 
-extern "C" int qtts_paged_attention(const void *q, int ldq, const void *k_cache, const void *v_cache,
-                                    const int32_t *block_tables, int max_blocks, const int32_t *row_seq,
-                                    const int32_t *context_lens, int max_context, float scale, void *out, int ldo,
-                                    int N, int Hq, int Hkv, void *workspace, qtts_stream_t stream) {
+// opks > 0: `out` in fragment order (act_index) for the prompt GEMM that reads it
+static int paged_attention_impl(const void *q, int ldq, const void *k_cache, const void *v_cache,
+                                const int32_t *block_tables, int max_blocks, const int32_t *row_seq,
+                                const int32_t *context_lens, int max_context, float scale, void *out, int ldo,
+                                int N, int Hq, int Hkv, void *workspace, qtts_stream_t stream, int opks) {
     QCHECK(q && k_cache && v_cache && block_tables && context_lens && out, "paged_attention: null pointer");
     QCHECK(N > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "paged_attention: bad head counts %d/%d", Hq, Hkv);
     QCHECK(ldq % 8 == 0 && ldq >= Hq * 128 && ldo >= Hq * 128, "paged_attention: bad strides");
@@ -1693,11 +1744,11 @@ extern "C" int qtts_paged_attention(const void *q, int ldq, const void *k_cache,
         if (G == 1)
             hipLaunchKernelGGL((prefill_attn_mfma_kernel<1>), grid, dim3(512), shmem, s, (const bf16_t *)q, ldq,
                                (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq,
-                               context_lens, scale, (bf16_t *)out, ldo, N, Hkv);
+                               context_lens, scale, (bf16_t *)out, ldo, N, Hkv, opks);
         else
             hipLaunchKernelGGL((prefill_attn_mfma_kernel<2>), grid, dim3(512), shmem, s, (const bf16_t *)q, ldq,
                                (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq,
-                               context_lens, scale, (bf16_t *)out, ldo, N, Hkv);
+                               context_lens, scale, (bf16_t *)out, ldo, N, Hkv, opks);
         QLAUNCH();
         return QTTS_OK;
     }
@@ -1708,7 +1759,7 @@ extern "C" int qtts_paged_attention(const void *q, int ldq, const void *k_cache,
     dim3 grid(N, Hkv, ns);
 #define QA(G_) case G_: hipLaunchKernelGGL((paged_attn_kernel<G_>), grid, dim3(256), 0, s, (const bf16_t *)q, ldq, \
         (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq, context_lens, scale, \
-        (bf16_t *)out, ldo, Hkv, part_o, part_ml, ns); break;
+        (bf16_t *)out, ldo, Hkv, part_o, part_ml, ns, opks); break;
     switch (G) {
         QA(1) QA(2) QA(4)
         default: QFAIL(QTTS_EINVAL, "paged_attention: unsupported q/kv head ratio %d", G);
@@ -1717,10 +1768,18 @@ extern "C" int qtts_paged_attention(const void *q, int ldq, const void *k_cache,
     QLAUNCH();
     if (ns > 1) {
         hipLaunchKernelGGL(attn_combine_kernel, dim3(N, Hq), dim3(128), 0, s, part_o, part_ml, context_lens,
-                           (bf16_t *)out, ldo, Hq, ns, ATT_SPLIT);
+                           (bf16_t *)out, ldo, Hq, ns, ATT_SPLIT, opks);
         QLAUNCH();
     }
     return QTTS_OK;
+}
+
+extern "C" int qtts_paged_attention(const void *q, int ldq, const void *k_cache, const void *v_cache,
+                                    const int32_t *block_tables, int max_blocks, const int32_t *row_seq,
+                                    const int32_t *context_lens, int max_context, float scale, void *out, int ldo,
+                                    int N, int Hq, int Hkv, void *workspace, qtts_stream_t stream) {
+    return paged_attention_impl(q, ldq, k_cache, v_cache, block_tables, max_blocks, row_seq, context_lens, max_context,
+                                scale, out, ldo, N, Hq, Hkv, workspace, stream, 0);
 }
 
 
@@ -2720,12 +2779,16 @@ struct LayerW {
 };
 
 // The decoder stack's GEMMs with bf16 or fp8 weights (wscale != null).
+// How a prompt GEMM's activations are laid out (all zero: row-major everywhere)
+struct ActLayout { int xpacked = 0, opks = 0, nnpks = 0; };
+
 static int stack_linear(const void *x, int ldx, const void *w, const float *wscale, const void *residual, int ldr,
                         const void *norm_w, float eps, void *out, int ldo, int M, int N, int K, float *scratch,
                         size_t scratch_bytes, qtts_stream_t stream, const void *next_norm_w = nullptr,
                         void *next_xn = nullptr, int ldnn = 0, const int64_t *x_ids = nullptr,
-                        const int64_t *res_ids = nullptr, int id_rows = 0) {
+                        const int64_t *res_ids = nullptr, int id_rows = 0, ActLayout lay = ActLayout()) {
     LinArgs a;
+    a.xpacked = lay.xpacked; a.opks = lay.opks; a.nnpks = lay.nnpks;
     a.next_nw = (const bf16_t *)next_norm_w; a.next_xn = (bf16_t *)next_xn; a.ldnn = ldnn;
     a.res_ids = res_ids; a.res_id_rows = res_ids ? id_rows : 0;
     a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = x_ids; a.id_rows = x_ids ? id_rows : 0; a.wp = (const uint4 *)w; a.wscale = wscale;
@@ -2735,8 +2798,9 @@ static int stack_linear(const void *x, int ldx, const void *w, const float *wsca
 }
 
 static int stack_swiglu(const void *x, int ldx, const void *wgu, const float *wscale, const void *norm_w, float eps,
-                        void *out, int ldo, int M, int I, int K, qtts_stream_t stream) {
+                        void *out, int ldo, int M, int I, int K, qtts_stream_t stream, ActLayout lay = ActLayout()) {
     LinArgs a;
+    a.xpacked = lay.xpacked; a.opks = lay.opks; a.nnpks = lay.nnpks;
     a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0; a.wp = (const uint4 *)wgu; a.wscale = wscale;
     a.bias = nullptr; a.res = nullptr; a.ldr = 0; a.nw = (const bf16_t *)norm_w; a.eps = eps; a.xnorm_out = nullptr;
     a.ldxn = 0; a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = 2 * I; a.K = K; a.tiles_per_wg = 1;
@@ -2878,11 +2942,12 @@ static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
     size_t off = 0;
     const size_t qkvw = (size_t)(m->n_heads + 2 * m->n_kv_heads) * 128;
     L.qkv = off; off += align256((size_t)rows * qkvw * 2);
-    L.attn = off; off += align256((size_t)rows * m->n_heads * 128 * 2);
-    L.act = off; off += align256((size_t)rows * m->inter * 2);
+    const size_t rows16 = ((size_t)rows + 15) & ~(size_t)15;      // fragment-order buffers hold whole 16-row tiles
+    L.attn = off; off += align256(rows16 * m->n_heads * 128 * 2);
+    L.act = off; off += align256(rows16 * m->inter * 2);
     L.xa = off; off += align256((size_t)rows * m->hidden * 2);
     L.xb = off; off += align256((size_t)rows * m->hidden * 2);
-    L.xn = off; off += align256((size_t)rows * m->hidden * 2);       // normalised rows of a prompt (prefill GEMMs)
+    L.xn = off; off += align256(rows16 * m->hidden * 2);              // normalised rows of a prompt (prefill GEMMs)
     L.parts_bytes = linear_rows_scratch_bytes(rows, m->hidden, m->inter);   // K parts of a prompt's down projection
     L.parts = off; off += align256(L.parts_bytes);
     // prefill and decode attention share the partials region; the decode kernel's arrival counters follow it.
@@ -2964,6 +3029,17 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     // rides in the GEMM prologue.
     const bool split_norm = N > 16;
     const int qkvw = (Hq + 2 * Hkv) * 128;
+    // A prompt whose four GEMMs per layer all run as the row-stationary prompt kernel hands the activations between
+    // the kernels of a layer (normalised rows, attention output, SwiGLU output) over in fragment order: that kernel
+    // then reads one contiguous KiB per request.  The residual stream, qkv and everything returned stay row-major.
+    const bool frag = split_norm && !pairs &&
+                      linear_rows_covers(N, qkvw, H, false, false, false, 0) &&
+                      linear_rows_covers(N, H, Hq * 128, false, false, false, 0) &&
+                      linear_rows_covers(N, 2 * m->inter, H, true, false, false, 0) &&
+                      linear_rows_covers(N, H, m->inter, false, false, true, W.parts_bytes);
+    const int pkH = frag ? H / 32 : 0, pkA = frag ? Hq * 128 / 32 : 0, pkI = frag ? m->inter / 32 : 0;
+    ActLayout lay_in;                                  // a GEMM reading fragment-order rows
+    lay_in.xpacked = frag;
     const float scale = 1.0f / sqrtf((float)m->head_dim);
     const size_t layer_kv = (size_t)m->num_blocks * QTTS_KV_BLOCK * Hkv * 128 * 2;   // bytes per layer per K or V
     const bf16_t *cur = (const bf16_t *)x;
@@ -2975,9 +3051,10 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         char *kc = m->kv + (size_t)l * layer_kv;
         char *vc = m->kv + ((size_t)m->n_layers + l) * layer_kv;
         if (split_norm) {
-            if (!xn_ready && (rc = qtts_rmsnorm(cur, H, L.in_norm, m->eps, xn, H, N, H, stream))) return rc;
+            if (!xn_ready && (rc = rmsnorm_impl(cur, H, L.in_norm, m->eps, xn, H, N, H, pkH, stream))) return rc;
             xn_ready = false;
-            if ((rc = stack_linear(xn, H, L.wqkv, L.s_qkv, nullptr, 0, nullptr, 0.f, qkv, qkvw, N, qkvw, H, nullptr, 0, stream)))
+            if ((rc = stack_linear(xn, H, L.wqkv, L.s_qkv, nullptr, 0, nullptr, 0.f, qkv, qkvw, N, qkvw, H, nullptr, 0, stream,
+                                   nullptr, nullptr, 0, nullptr, nullptr, 0, lay_in)))
                 return rc;
         } else if (l == 0 && qkv0_rows) {
             // layer 0's normalised, projected rows come from the table
@@ -3000,18 +3077,21 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         } else {
             if ((rc = qtts_qknorm_rope_store(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
                                              positions, slot_mapping, kc, vc, N, Hq, Hkv, stream))) return rc;
-            if ((rc = qtts_paged_attention(qkv, qkvw, kc, vc, block_tables, max_blocks, row_seq, context_lens,
-                                           max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws, stream))) return rc;
+            if ((rc = paged_attention_impl(qkv, qkvw, kc, vc, block_tables, max_blocks, row_seq, context_lens,
+                                           max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws, stream, pkA))) return rc;
         }
         {
             LayerEventScope ev(m, l, QTTS_LAUNCH_O_PROJ, stream);
             if ((rc = stack_linear(attn, Hq * 128, L.wo, L.s_o, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, nullptr, 0, stream,
-                                   nullptr, nullptr, 0, nullptr, l == 0 ? x_ids : nullptr, x_id_rows)))
+                                   nullptr, nullptr, 0, nullptr, l == 0 ? x_ids : nullptr, x_id_rows,
+                                   decode || pairs ? ActLayout() : lay_in)))
                 return rc;
         }
         if (split_norm) {
-            if ((rc = qtts_rmsnorm(xa, H, L.post_norm, m->eps, xn, H, N, H, stream))) return rc;
-            if ((rc = stack_swiglu(xn, H, L.wgu, L.s_gu, nullptr, 0.f, act, m->inter, N, m->inter, H, stream))) return rc;
+            ActLayout lay_gu = lay_in;
+            lay_gu.opks = pkI;
+            if ((rc = rmsnorm_impl(xa, H, L.post_norm, m->eps, xn, H, N, H, pkH, stream))) return rc;
+            if ((rc = stack_swiglu(xn, H, L.wgu, L.s_gu, nullptr, 0.f, act, m->inter, N, m->inter, H, stream, lay_gu))) return rc;
         } else {
             LayerEventScope ev(m, l, QTTS_LAUNCH_GATE_UP, stream);
             if ((rc = stack_swiglu(xa, H, L.wgu, L.s_gu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
@@ -3021,10 +3101,13 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         const bool last = l + 1 == m->n_layers;
         const bool fuse_next = split_norm && linear_rows_is_ksplit(N, H, m->inter, W.parts_bytes);
         LayerEventScope ev_down(m, l, QTTS_LAUNCH_DOWN, stream);
+        ActLayout lay_down;
+        lay_down.xpacked = split_norm ? frag : 0;
+        lay_down.nnpks = fuse_next && !last ? pkH : 0;   // the next layer's normalised rows; the returned hidden state stays row-major
         if ((rc = stack_linear(act, m->inter, L.wdown, L.s_down, xa, H, nullptr, fuse_next ? m->eps : 0.f, xb, H, N, H, m->inter,
                                (float *)(m->ws + W.parts), W.parts_bytes, stream,
                                fuse_next ? (last ? m->final_norm : m->layers[l + 1].in_norm) : nullptr,
-                               fuse_next ? (last ? (bf16_t *)hidden_out : xn) : nullptr, H))) return rc;
+                               fuse_next ? (last ? (bf16_t *)hidden_out : xn) : nullptr, H, nullptr, nullptr, 0, lay_down))) return rc;
         if (fuse_next) (last ? final_ready : xn_ready) = true;
         // Fixed roles: xa = post-attention residual stream, xb = layer output.  The next layer reads xb
         // (qkv GEMM, o_proj residual) before its down_proj overwrites it, all stream-ordered.

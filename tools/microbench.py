@@ -313,7 +313,7 @@ def rows():
             continue
         ws_w = [(torch.randn(N * K // 4, device=dev) * 0.02).bfloat16().repeat(4) for _ in range(nl)]
         for M in [int(v) for v in os.environ.get("QTTS_ROWS", "32,64,128,200,400").split(",")]:
-            x = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
+            x = (torch.randn(M + 16, K, device=dev) * 0.5).bfloat16()[:M]     # (room for a padded last row tile)
             res = torch.randn(M, N, device=dev).bfloat16()
             out = torch.empty(M, N // 2 if kind == "swiglu" else N, dtype=torch.bfloat16, device=dev)
 
