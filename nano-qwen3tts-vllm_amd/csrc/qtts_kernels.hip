@@ -853,6 +853,24 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
 #undef QTTS_RTRACE
 }
 
+// Sum of the K parts of one output quad, part 0 first.  Up to four parts are requested together (a loop over a
+// run-time count waits for each part before it asks for the next).
+__device__ __forceinline__ float4_t sum_k_parts(const float *part, size_t first, size_t part_stride, int kparts) {
+    if (kparts <= 4) {
+        float4_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            v[k] = *reinterpret_cast<const float4_t *>(part + first + (size_t)(k < kparts ? k : kparts - 1) * part_stride);
+        float4_t sum = v[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) sum = k < kparts ? sum + v[k] : sum;
+        return sum;
+    }
+    float4_t sum = *reinterpret_cast<const float4_t *>(part + first);
+    for (int k = 1; k < kparts; ++k) sum += *reinterpret_cast<const float4_t *>(part + first + (size_t)k * part_stride);
+    return sum;
+}
+
 // Sum of the K parts + the bias/residual epilogue (same rounding points as the single-launch epilogue).
 __global__ __launch_bounds__(256) void linear_parts_kernel(const float *part, int kparts, int mpad, int M, int N,
                                                            const bf16_t *bias, const bf16_t *res, int ldr, bf16_t *out, int ldo) {
@@ -860,8 +878,7 @@ __global__ __launch_bounds__(256) void linear_parts_kernel(const float *part, in
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)M * n4) return;
     const int m = (int)(idx / n4), n = (int)(idx % n4) * 4;
-    float4_t sum = *reinterpret_cast<const float4_t *>(part + (size_t)m * N + n);
-    for (int k = 1; k < kparts; ++k) sum += *reinterpret_cast<const float4_t *>(part + ((size_t)k * mpad + m) * N + n);
+    const float4_t sum = sum_k_parts(part, (size_t)m * N + n, (size_t)mpad * N, kparts);
     float v[4], rf[4] = {0.f, 0.f, 0.f, 0.f}, bfv[4] = {0.f, 0.f, 0.f, 0.f};
     if (res) {
         const uint2 w = *reinterpret_cast<const uint2 *>(res + (size_t)m * ldr + n);
@@ -898,8 +915,7 @@ __global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *par
         float q[8];
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
-            float4_t sum = *reinterpret_cast<const float4_t *>(part + (size_t)m * N + n + 4 * hlf);
-            for (int k = 1; k < kparts; ++k) sum += *reinterpret_cast<const float4_t *>(part + ((size_t)k * mpad + m) * N + n + 4 * hlf);
+            const float4_t sum = sum_k_parts(part, (size_t)m * N + n + 4 * hlf, (size_t)mpad * N, kparts);
 #pragma unroll
             for (int j = 0; j < 4; ++j) q[4 * hlf + j] = sum[j];
         }
@@ -2024,15 +2040,30 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
     const bool direct = nact == 1;
     for (int e = threadIdx.x; e < G * 128; e += NT) {
         const int h = e >> 7, d = e & 127;
+        // every group's maximum, sum and accumulator element are read from LDS in batches before they are used (a
+        // loop that reads and accumulates in turn waits out one LDS latency per group: up to 32 of them here)
+        float mv[NG];
+#pragma unroll
+        for (int gI = 0; gI < NG; ++gI) mv[gI] = sm_m[gI][h];
         float M = -INFINITY;
 #pragma unroll
-        for (int gI = 0; gI < NG; ++gI) M = fmaxf(M, sm_m[gI][h]);
+        for (int gI = 0; gI < NG; ++gI) M = fmaxf(M, mv[gI]);
         float L = 0.f, o = 0.f;
-#pragma unroll 8
-        for (int gI = 0; gI < NG; ++gI) {
-            const float wgt = __expf(sm_m[gI][h] - M);     // an empty group: exp(-inf) = 0
-            L += sm_l[gI][h] * wgt;
-            o += sm_acc[gI][h][d] * wgt;
+        constexpr int MB = NG < 16 ? NG : 16;
+#pragma unroll
+        for (int g0 = 0; g0 < NG; g0 += MB) {
+            float lv[MB], av[MB];
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                lv[j] = sm_l[g0 + j][h];
+                av[j] = sm_acc[g0 + j][h][d];
+            }
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                const float wgt = __expf(mv[g0 + j] - M);  // an empty group: exp(-inf) = 0
+                L += lv[j] * wgt;
+                o += av[j] * wgt;
+            }
         }
         const int hq = kvh * G + h;
         if (direct) {
@@ -2705,19 +2736,30 @@ __global__ __launch_bounds__(256) void frame_glue_kernel(const bf16_t *__restric
                                                          int H, int tv, int pv) {
     const int b = blockIdx.x;
     __shared__ long ids[16];
+    __shared__ const bf16_t *rows[16];
+    // ids, table pointers and the frame counter are requested together; the 16 rows' addresses go through LDS, so
+    // the row loads that follow the barrier depend on nothing else in memory
+    const int fidx = frame_idx ? frame_idx[b] : 0;
     if (threadIdx.x < 16) {
         long id = threadIdx.x == 0 ? token0[b] : pred_tokens[(size_t)(threadIdx.x - 1) * ldp + b];
+        const bf16_t *tab = threadIdx.x == 0 ? temb : ptabs[threadIdx.x - 1];
         if (codes) codes[b * 16 + threadIdx.x] = id;
         const int lim = threadIdx.x == 0 ? tv : pv;
-        ids[threadIdx.x] = id < 0 ? 0 : (id >= lim ? lim - 1 : id);
+        id = id < 0 ? 0 : (id >= lim ? lim - 1 : id);
+        ids[threadIdx.x] = id;
+        rows[threadIdx.x] = tab + (size_t)id * H;
     }
     __syncthreads();
-    const float *ta = text_add + (size_t)b * ld_text + (frame_idx ? (size_t)frame_idx[b] * H : 0);
+    const float *ta = text_add + (size_t)b * ld_text + (size_t)fidx * H;
     for (int d = threadIdx.x; d < H; d += 256) {
-        float s = bf2f(temb[(size_t)ids[0] * H + d]);
+        float v[16];
 #pragma unroll
-        for (int c = 1; c < 16; ++c) s += bf2f(ptabs[c - 1][(size_t)ids[c] * H + d]);
-        next[(size_t)b * H + d] = f2bf(s + ta[d]);
+        for (int c = 0; c < 16; ++c) v[c] = bf2f(rows[c][d]);
+        const float tv_ = ta[d];
+        float s = v[0];
+#pragma unroll
+        for (int c = 1; c < 16; ++c) s += v[c];
+        next[(size_t)b * H + d] = f2bf(s + tv_);
     }
 }
 

@@ -1,11 +1,14 @@
 #!/bin/bash
-# op tests, then the prompt-GEMM table, the in-kernel timeline and the bench line of the current build
+# tests with the current build, then the bench line with the previous build (csrc/libqtts_hip_prev.so, built by hand from
+# the last commit) and the current one in turn, on one box
 set -e -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ab; mkdir -p $O; cd $R
-timeout -k 10 600 python3 -u -m pytest -x -q --timeout 300 --timeout-method thread -m gpu tests/test_hip_ops.py tests/test_hip_fp8.py tests/test_hip_engine.py tests/test_hip_frame_engine.py > $O/tests.log 2>&1
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ab; rm -rf $O; mkdir -p $O; cd $R
+timeout -k 10 600 python3 -u -m pytest -x -q --timeout 300 --timeout-method thread -m gpu tests/test_hip_ops.py tests/test_hip_fp8.py tests/test_hip_engine.py tests/test_hip_frame_engine.py tests/test_zz_no_alloc.py > $O/tests.log 2>&1
+for i in 1 2 3; do
+  for v in prev cur; do
+    lib=$R/nano-qwen3tts-vllm_amd/csrc/libqtts_hip.so; [ $v = prev ] && lib=$R/nano-qwen3tts-vllm_amd/csrc/libqtts_hip_prev.so
+    QTTS_LIB=$lib timeout -k 10 200 python3 -u bench.py --no-cpu-baseline --no-arrivals --steps 200 > $O/bench_${v}_$i.json 2>/dev/null
+  done
+done
 cd tools
-QTTS_ROWS=32,64,200,400 timeout -k 10 200 python3 -u microbench.py rows > $O/rows.txt 2>/dev/null
-QTTS_ROWS=200 timeout -k 10 100 python3 -u microbench.py rowtrace > $O/rowtrace.txt 2>/dev/null
 QTTS_FRAME_PROMPT=16,48,128,200,400 timeout -k 10 200 python3 -u microbench.py prefill > $O/prefill.txt 2>/dev/null
-cd $R
-timeout -k 10 200 python3 -u bench.py --no-cpu-baseline > $O/bench.json 2>/dev/null
