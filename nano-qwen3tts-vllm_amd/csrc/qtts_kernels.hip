@@ -2589,6 +2589,63 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const bf16_t *__restri
     }
     const float maxv = best;
     // ---- k-th largest value
+    float kth;
+    if (vec) {
+        // logits / T is monotone in the bf16 logit (T > 0), so the k-th largest is found on the 16-bit keys of the raw
+        // logits, which every thread still holds in registers: two 8-bit passes instead of four over the 32-bit
+        // keys of the staged values, no LDS reads in a pass, and three barriers per pass (the histogram of the next
+        // pass is cleared while this one is scanned).
+        __shared__ int hist2[2][256];
+        uint32_t k16[2][8];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint32_t u = f[c].h[j];
+                if (u == 0x8000u) u = 0;                              // -0 and +0 are one value
+                k16[c][j] = (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
+            }
+        hist2[0][threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t prefix = 0, mask = 0;
+        int krem = top_k;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int shift = 8 - 8 * pass;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if ((int)threadIdx.x + 256 * c < nch) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if ((k16[c][j] & mask) == prefix) atomicAdd(&hist2[pass][(k16[c][j] >> shift) & 255], 1);
+                }
+            __syncthreads();
+            const int cnt = hist2[pass][255 - threadIdx.x];           // thread t looks at bin 255 - t: counts from the top
+            if (pass == 0) hist2[1][threadIdx.x] = 0;
+            int x = cnt;
+            const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(x, o);
+                if (lane >= o) x += y;
+            }
+            if (lane == 63) wi[w] = x;
+            __syncthreads();
+            int off = 0;
+            for (int i = 0; i < w; ++i) off += wi[i];
+            const int incl = x + off;
+            if (incl >= krem && incl - cnt < krem) {                  // exactly one thread
+                sel[0] = 255 - threadIdx.x;
+                sel[1] = krem - (incl - cnt);
+            }
+            __syncthreads();
+            prefix |= (uint32_t)sel[0] << shift;
+            mask |= 0xffu << shift;
+            krem = sel[1];
+        }
+        const uint32_t kb = (prefix & 0x8000u) ? (prefix & 0x7fffu) : (~prefix & 0xffffu);
+        kth = bf2f((bf16_t)kb) / T;
+    } else {
     uint32_t prefix = 0, mask = 0;
     int krem = top_k;
 #pragma unroll 1
@@ -2612,7 +2669,8 @@ __global__ __launch_bounds__(256) void sample_topk_kernel(const bf16_t *__restri
         krem = sel[1];
         __syncthreads();
     }
-    const float kth = fkey_inv(prefix);
+    kth = fkey_inv(prefix);
+    }
     // ---- softmax weights over values >= kth (ties at the threshold all stay, as `logits < kth` removes only smaller
     // ones), a chunk of consecutive indices per thread
     const int C = (V + 255) >> 8;
