@@ -497,6 +497,16 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         rres = rres < 0 ? 0 : (rres >= p.id_rows ? p.id_rows - 1 : rres);
         rrow = (size_t)rres * p.ldr;
     }
+    // Single-tile launches: the tile's residual / bias words are requested HERE, directly behind the weight requests
+    // and before anything waits for the activations.  Requested inside the tile body they went out only after the
+    // activations had arrived and been prepared, i.e. one round trip late, and since the compiler must assume that
+    // a request under a condition may not have been made, its wait for the last weight fragment also waited for
+    // them: the launch then took two round trips one after the other instead of one.
+    uint2 resw_first = make_uint2(0, 0), biasw_first = make_uint2(0, 0);
+    if (!DB && EPI == 0 && wave == 0 && orow) {
+        if (p.res && mvalid) resw_first = *reinterpret_cast<const uint2 *>(p.res + rrow + 16 * t_begin + 4 * g);
+        if (p.bias) biasw_first = *reinterpret_cast<const uint2 *>(p.bias + 16 * t_begin + 4 * g);
+    }
     float *normred = reinterpret_cast<float *>(smem4 + (size_t)2 * NW * 64);
     if (PRO == 1) {
         // sum of squares: even k-steps, odd k-steps, then their sum (H8: the odd ones are the partner lane's)
@@ -555,8 +565,8 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         // The wave that finishes a tile (cross-wave sum, epilogue, store) alternates between waves 0 and 1: the
         // finishing of tile t then overlaps the multiplications of tile t + 1 instead of preceding them in one wave.
         const bool finisher = wave == (NW > 1 ? (it & 1) : 0);
-        uint2 resw = make_uint2(0, 0), biasw = make_uint2(0, 0);
-        if (EPI == 0 && finisher && orow) {
+        uint2 resw = resw_first, biasw = biasw_first;
+        if (DB && EPI == 0 && finisher && orow) {
             if (p.res && mvalid) resw = *reinterpret_cast<const uint2 *>(p.res + rrow + 16 * t + 4 * g);
             if (p.bias) biasw = *reinterpret_cast<const uint2 *>(p.bias + 16 * t + 4 * g);
         }
