@@ -1072,7 +1072,7 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     r.trace = g_trace;
 #endif
     r.wscale = a.wscale;
-    r.xpacked = a.xpacked; r.opks = a.opks; r.xnpks = a.nnpks;
+    r.xpacked = a.xpacked || (g_dbg_linear & 64); r.opks = a.opks; r.xnpks = a.nnpks;   // (bit 6: timing experiments read x in fragment order)
     const int ntiles = a.N / 16;
     // One round of workgroups (a CU holds one, an XCD 32): workgroup i runs on XCD i % 8 and the launch is laid out
     // in groups of 8 column blocks x all row groups (x K parts), so the groups of 8 that fit one round are

@@ -342,9 +342,10 @@ def rowtrace():
     which = os.environ.get("QTTS_ROWS_ONLY", "gate_up")
     N, K = {"gate_up": (2 * I, H), "down": (H, I), "qkv": (4096, H), "o_proj": (H, H)}[which]
     ws = [(torch.randn(N * K // 4, device=dev) * 0.02).bfloat16().repeat(4) for _ in range(4)]
-    x = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
+    x = (torch.randn(M + 16, K, device=dev) * 0.5).bfloat16()[:M]       # (room for a padded last row tile)
     out = torch.empty(M, I if which == "gate_up" else N, dtype=torch.bfloat16, device=dev)
     buf = torch.zeros(1024 * 32, dtype=torch.int64, device=dev)
+    hip.lib.qtts_debug_linear(int(os.environ.get("QTTS_LINEAR_DBG", "0")))
 
     def call(w):
         if which == "gate_up":

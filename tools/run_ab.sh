@@ -7,8 +7,13 @@ timeout -k 10 600 python3 -u -m pytest -x -q --timeout 300 --timeout-method thre
 for i in 1 2 3; do
   for v in prev cur; do
     lib=$R/nano-qwen3tts-vllm_amd/csrc/libqtts_hip.so; [ $v = prev ] && lib=$R/nano-qwen3tts-vllm_amd/csrc/libqtts_hip_prev.so
-    QTTS_LIB=$lib timeout -k 10 200 python3 -u bench.py --no-cpu-baseline --no-arrivals --steps 200 > $O/bench_${v}_$i.json 2>/dev/null
+    extra="--no-arrivals"; [ $i = 1 ] && extra=""
+    QTTS_LIB=$lib timeout -k 10 200 python3 -u bench.py --no-cpu-baseline $extra --steps 200 > $O/bench_${v}_$i.json 2>/dev/null
   done
 done
-cd tools
-QTTS_FRAME_PROMPT=16,48,128,200,400 timeout -k 10 200 python3 -u microbench.py prefill > $O/prefill.txt 2>/dev/null
+for S in 64 128; do
+  for v in prev cur; do
+    lib=$R/nano-qwen3tts-vllm_amd/csrc/libqtts_hip.so; [ $v = prev ] && lib=$R/nano-qwen3tts-vllm_amd/csrc/libqtts_hip_prev.so
+    QTTS_LIB=$lib timeout -k 10 200 python3 -u bench.py --no-cpu-baseline --no-arrivals --streams $S --steps 50 > $O/sweep_${v}_$S.json 2>/dev/null
+  done
+done
