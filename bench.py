@@ -447,7 +447,7 @@ def main():
         traffic, traffic_src = pmc_traffic() if stored else (None, None)
         prof_us, prof_src = profiler_duration() if stored else (None, None)
         out = {
-            "metric": "codec tokens/sec at 8 concurrent streams per GPU (RTF alongside), Qwen3-TTS-1.7B",
+            "metric": f"codec tokens/sec at {B} concurrent streams per GPU (RTF alongside), Qwen3-TTS-{args.size}",
             "value": value, "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.weights == "bf16" else "bf16 (weights stored as fp8 e4m3, converted in registers)",

@@ -36,7 +36,7 @@ def main():
     for name in ("fetch", "write"):
         shutil.copy(glob.glob(os.path.join(R, f"pmc_{name}", "vm", "*counter_collection.csv"))[0],
                     os.path.join(P, f"r02_pmc_{name}_counter_collection.csv"))
-    for f in ("bench_2rank_rehearsal", "api_quick_benchmark", "api_batch_async_fused", "api_batch_async_workers",
+    for f in ("config_0.6B_1stream", "config_fp8_8streams", "bench_2rank_rehearsal", "api_quick_benchmark", "api_batch_async_fused", "api_batch_async_workers",
               "api_batch_async_fused_sampling", "api_quick_benchmark_sampling"):
         src = os.path.join(R, f + ".json")
         if os.path.exists(src):

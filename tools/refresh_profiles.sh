@@ -27,6 +27,10 @@ cd $R
 QTTS_OVERLAP_PREFILL=1 timeout -k 10 300 python3 -u bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_overlap1.json 2>> $O/err.log
 step two-ranks
 QTTS_BENCH_REHEARSAL=1 timeout -k 10 400 python3 -u bench.py --gpus 2 --steps 50 --warmup 5 > $O/bench_2rank_rehearsal.json 2>> $O/err.log
+step configs
+# BASELINE.json's other configurations as bench lines of their own: 0.6B shapes with one stream; fp8 weights at 8 streams
+timeout -k 10 300 python3 -u bench.py --size 0.6B --streams 1 --steps 100 --no-cpu-baseline > $O/config_0.6B_1stream.json 2>> $O/err.log
+timeout -k 10 300 python3 -u bench.py --weights fp8 --steps 100 --no-cpu-baseline > $O/config_fp8_8streams.json 2>> $O/err.log
 step examples
 cd $R
 timeout -k 10 300 python3 -u examples/quick_benchmark.py > $O/api_quick_benchmark.json 2> $O/qb.err
