@@ -987,6 +987,12 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
     tl.wscale = a.wscale;
     if constexpr (KSW % 2 == 0 && PRO != 2) {
         if (a.wscale) {
+            // fp8 weights: the activation prologue is the bf16 kernels', shared lanes for at most 8 rows included
+            if (CAN_H8 && a.M <= 8 && !(a.dbg >> 8) && g_share_prologue) {
+                QTTS_LAUNCH_MAYBE_TIMED((linear2_kernel<KSW, PRO, DB, EPI, SUB, true, CAN_H8>), grid, dim3(NW * 64), shmem, s, a.x,
+                                        a.wp, a.ids, a.ldx, a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
+                return;
+            }
             QTTS_LAUNCH_MAYBE_TIMED((linear2_kernel<KSW, PRO, DB, EPI, SUB, true>), grid, dim3(NW * 64), shmem, s, a.x, a.wp, a.ids,
                                     a.ldx, a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
             return;
@@ -1072,7 +1078,7 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     r.trace = g_trace;
 #endif
     r.wscale = a.wscale;
-    r.xpacked = a.xpacked || (g_dbg_linear & 64); r.opks = a.opks; r.xnpks = a.nnpks;   // (bit 6: timing experiments read x in fragment order)
+    r.xpacked = (g_dbg_linear & 64) != 0 ? 1 : a.xpacked; r.opks = a.opks; r.xnpks = a.nnpks;   // (bit 6: timing experiments read x in fragment order)
     const int ntiles = a.N / 16;
     // One round of workgroups (a CU holds one, an XCD 32): workgroup i runs on XCD i % 8 and the launch is laid out
     // in groups of 8 column blocks x all row groups (x K parts), so the groups of 8 that fit one round are

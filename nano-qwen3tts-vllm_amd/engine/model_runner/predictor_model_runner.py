@@ -64,7 +64,7 @@ class PredictorModelRunner(ModelRunner):
         # projection of every table row, and layer 0's input norm + qkv projection of it, depend on the weights
         # only and are computed once here with the same GEMM launches a step would use (same bits); a step then
         # gathers instead of projecting.  QTTS_FOLD_INPUT=0 keeps the per-step launches.
-        self.fold = os.environ.get("QTTS_FOLD_INPUT", "1") == "1" and self.decoder.weight_dtype == "bf16"
+        self.fold = os.environ.get("QTTS_FOLD_INPUT", "1") == "1"
         self.pair_prefill = os.environ.get("QTTS_PAIR_PREFILL", "1") == "1"   # 0: the general prompt path
         self.x_tables, self.qkv0_tables = [], []
         if self.fold:
@@ -120,6 +120,11 @@ class PredictorModelRunner(ModelRunner):
             qt = torch.empty(rows, qkvw, dtype=torch.bfloat16, device=self.device)
             for c in range(0, rows, 16):
                 n = min(16, rows - c)
+                if d.layer0_qkv_scales is not None:       # fp8 weights: the fp8 launch a step would make
+                    hip.check(lib.qtts_linear_fp8(hip.ptr(xt) + 2 * c * h, h, hip.ptr(d.layer0_wqkv), hip.ptr(d.layer0_qkv_scales),
+                                                  None, None, 0, hip.ptr(d.layer0_in_norm), s.rms_eps,
+                                                  hip.ptr(qt) + 2 * c * qkvw, qkvw, n, qkvw, h, None, 0, hip.stream()), "fold qkv0")
+                    continue
                 hip.check(lib.qtts_linear_fused(hip.ptr(xt) + 2 * c * h, h, None, 0, hip.ptr(d.layer0_wqkv), None, None, 0,
                                                 hip.ptr(d.layer0_in_norm), s.rms_eps, None, 0, 0,
                                                 hip.ptr(qt) + 2 * c * qkvw, qkvw, n, qkvw, h, hip.stream()), "fold qkv0")

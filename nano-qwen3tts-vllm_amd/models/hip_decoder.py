@@ -92,7 +92,8 @@ class HipDecoder:
                      dev(weights[p + "self_attn.k_norm.weight"]), dev(weights[p + "post_attention_layernorm.weight"])]
             self._keep += [wqkv_p, wo_p, wgu_p, wd_p]
             if i == 0:
-                self.layer0_in_norm, self.layer0_wqkv = norms[0], wqkv_p     # for tables of layer-0 rows (bf16 weights)
+                self.layer0_in_norm, self.layer0_wqkv = norms[0], wqkv_p     # for tables of layer-0 rows
+                self.layer0_qkv_scales = s_qkv if fp8 else None
             self.packed_gate_up = getattr(self, "packed_gate_up", []) + [wgu_p]
             P = hip.ptr
             if fp8:

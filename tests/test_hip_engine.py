@@ -146,8 +146,9 @@ def test_predictor_engine_burst_matches_reference_fixture(setup, burst, monkeypa
     llm.exit()
 
 
-def test_folded_input_tables_give_the_same_bits(monkeypatch, tmp_path):
-    """1.7B predictor shapes, 8 sequences: a burst whose decode steps read the projected embedding rows and layer 0's
+@pytest.mark.parametrize("weights", ["bf16", "fp8"])
+def test_folded_input_tables_give_the_same_bits(monkeypatch, tmp_path, weights):
+    """(with bf16 weights and with the layers' weights stored as fp8)  1.7B predictor shapes, 8 sequences: a burst whose decode steps read the projected embedding rows and layer 0's
     qkv rows from tables built at load (QTTS_FOLD_INPUT=1, the default) returns bit for bit what the burst that
     gathers, projects and runs layer 0's qkv GEMM every step returns: ids, last logits and last hidden state.
     (P/models/qwen3_tts_predictor.py:87-99,106; P/models/qwen3_tts_share.py:96-99)"""
@@ -169,11 +170,12 @@ def test_folded_input_tables_give_the_same_bits(monkeypatch, tmp_path):
     gen = torch.Generator().manual_seed(4)
     pin = (torch.randn(8, 2, cfg["talker_config"]["hidden_size"], generator=gen) * 0.5).bfloat16()
     res = {}
+    monkeypatch.setenv("QTTS_WEIGHT_DTYPE", weights)
     for fold in ("1", "0"):
         monkeypatch.setenv("QTTS_FOLD_INPUT", fold)
         llm = PredictorLLM(str(tmp_path), weights=pw, num_kvcache_blocks=8, max_num_seqs=8, max_num_batched_tokens=1024)
         mr = llm.model_runner
-        assert mr.fold == (fold == "1")
+        assert mr.fold == (fold == "1") and mr.decoder.weight_dtype == weights
         if mr.fold:
             # a table row is what the per-step launch computes for that id
             from nano_qwen3tts_vllm import hip
