@@ -8,8 +8,10 @@ front-end that turns text, instruction, speaker, language and a ready voice-clon
 embeddings (`generate_voice_design`, `generate_custom_voice(_async)`, `generate_voice_clone(_async)`,
 reference :723-1171, on utils/generation.py + utils/prompt.py).  The text entry points need the tokenizer
 files in the model directory (or a `processor` assigned by the caller) and the text tables in the
-checkpoint.  Reference audio -> voice-clone prompt (speaker encoder, speech codec) and codes -> PCM live in
-third-party packages; `create_voice_clone_prompt` keeps its signature and raises NotImplementedError.
+checkpoint.  The networks behind reference audio -> voice-clone prompt (speaker encoder, speech codec) and codes -> PCM
+live in third-party packages: `create_voice_clone_prompt` does the audio handling and the mel front-end itself
+(utils/ref_audio.py) and calls those networks through `speech_tokenizer` / `speaker_encoder`, raising
+RuntimeError when they are absent.
 """
 from __future__ import annotations
 
@@ -498,8 +500,50 @@ class Qwen3TTSInterface:
         async for frame in self.generate_async(embeds, trailing, pad, mask):
             yield frame
 
+    # ---------------------------------------------------------------- reference audio -> voice-clone prompt
+    def _load_speaker_encoder(self):
+        """The speaker encoder is a module of the third-party `qwen_tts` model class (the reference builds the whole
+        model on the CPU to take it out, P/interface.py:442-470).  Callers that hold it already assign
+        `interface.speaker_encoder` (any module: mel [1, frames, 128] -> [1, D])."""
+        if self.speaker_encoder is not None:
+            return self.speaker_encoder
+        try:
+            from qwen_tts.core.models import Qwen3TTSForConditionalGeneration
+        except ImportError as e:
+            raise RuntimeError("Speaker encoder not available for this model: the `qwen_tts` package is not installed "
+                               "and no `interface.speaker_encoder` was assigned") from e
+        whole = Qwen3TTSForConditionalGeneration.from_pretrained(self.model_path, device_map="cpu")
+        enc = getattr(whole, "speaker_encoder", None)
+        if enc is None:
+            raise RuntimeError("Model does not have speaker_encoder")
+        enc = enc.to(self.device)
+        if hasattr(whole, "dtype"):
+            enc = enc.to(whole.dtype)
+        self.speaker_encoder = enc
+        return enc
+
+    @torch.inference_mode()
+    def extract_speaker_embedding(self, audio, sr: int) -> torch.Tensor:
+        """24 kHz waveform -> speaker vector [D]: 128-band mel spectrogram (1024-point transform, hop 256, 0-12 kHz)
+        through the speaker encoder in its own dtype (P/interface.py:558-589)."""
+        from .utils.ref_audio import MEL_ARGS, SPEAKER_SR, mel_spectrogram
+        assert sr == SPEAKER_SR, "Only support 24kHz audio"
+        enc = self._load_speaker_encoder()
+        mels = mel_spectrogram(torch.as_tensor(audio, dtype=torch.float32).unsqueeze(0), **MEL_ARGS).transpose(1, 2)
+        dtype = next(enc.parameters()).dtype
+        return enc(mels.to(self.device).to(dtype))[0]
+
     def create_voice_clone_prompt(self, ref_audio, ref_text=None, x_vector_only_mode: bool = False):
-        raise NotImplementedError(
-            "create_voice_clone_prompt: turning reference audio into codec frames and a speaker vector needs the speech "
-            "codec and the speaker encoder, which ship in third-party packages outside this build; pass a ready "
-            "`voice_clone_prompt` dict (ref_code, ref_spk_embedding, x_vector_only_mode, icl_mode, ref_text) instead")
+        """Reference clip (path / URL / base64 / (waveform, sample_rate)) -> the dict generate_voice_clone takes:
+        ref_code [T,16] from the speech codec's encoder (None in x-vector-only mode), ref_spk_embedding [D],
+        x_vector_only_mode, icl_mode, ref_text (P/interface.py:670-721)."""
+        from .utils.ref_audio import SPEAKER_SR, normalize_audio_inputs, resample
+        if self.speech_tokenizer is None:
+            raise RuntimeError("speech_tokenizer not available. Cannot create voice clone prompt.")
+        if not x_vector_only_mode and not ref_text:
+            raise ValueError("ref_text is required when x_vector_only_mode=False (ICL mode).")
+        wav, sr = normalize_audio_inputs([ref_audio])[0]
+        ref_code = self.speech_tokenizer.tokenizer.encode(wav, sr=sr).audio_codes[0].cpu()       # [time, 16]
+        spk = self.extract_speaker_embedding(resample(wav, sr, SPEAKER_SR), SPEAKER_SR)
+        return {"ref_code": None if x_vector_only_mode else ref_code, "ref_spk_embedding": spk,
+                "x_vector_only_mode": bool(x_vector_only_mode), "icl_mode": not x_vector_only_mode, "ref_text": ref_text}

@@ -210,8 +210,8 @@ def test_interface_rejects_missing_path_and_front_end(model_dir):
     iface = Qwen3TTSInterface(model_dir)
     with pytest.raises(RuntimeError, match="no tokenizer"):
         iface.generate_voice_design("hi", "a calm voice")          # the synthetic directory has no tokenizer files
-    with pytest.raises(NotImplementedError):
-        iface.create_voice_clone_prompt(ref_audio="ref.wav", ref_text="hello")
+    with pytest.raises(RuntimeError, match="speech_tokenizer not available"):
+        iface.create_voice_clone_prompt(ref_audio="ref.wav", ref_text="hello")      # no speech codec package here
     with pytest.raises(AssertionError):
         Qwen3TTSInterface(model_dir, tensor_parallel_size=2)
 

@@ -141,7 +141,7 @@ def test_interface_front_end_builds_the_same_prompts(fe):
     same(iface._prep_voice_clone("Clone this voice please.", "English", None, None, False, vc, False), g, "clone_icl_short")
     with pytest.raises(ValueError):
         iface._prep_voice_clone("x", "English", None, None, False, dict(vc, ref_text=None), False)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="speech_tokenizer not available"):
         iface._prep_voice_clone("x", "English", "ref.wav", "words", False, None, True)
 
 
