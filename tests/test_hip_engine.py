@@ -278,7 +278,9 @@ def test_frame_loop_ids_match_reference_fixture(setup):
 
 
 @pytest.mark.parametrize("size,weights,prompt_lens", [("1.7B", "bf16", (9, 40)), ("0.6B", "bf16", (9, 40)),
-                                                      ("1.7B", "bf16", (130, 270)), ("1.7B", "fp8", (130, 270))])
+                                                      ("1.7B", "bf16", (130, 270)), ("1.7B", "fp8", (130, 270)),
+                                                      ("1.7B", "bf16", (5, 9, 16, 33, 64, 100, 17, 40)),
+                                                      ("1.7B", "bf16", (7, 12, 20, 33, 48, 5, 9, 70, 16, 25, 31, 64))])
 def test_full_size_frames_match_oracle(size, weights, prompt_lens, tmp_path, monkeypatch):
     """The released checkpoints' shapes (28 + 5 layers; 1.7B: hidden 2048 with the 2048 -> 1024 projection in front of
     the predictor, 0.6B: hidden 1024, no projection), random weights with spread-out heads, 2 streams (prompts of 9
@@ -293,7 +295,9 @@ def test_full_size_frames_match_oracle(size, weights, prompt_lens, tmp_path, mon
     Prompts of 130 and 270 tokens (voice-clone length: the prompt GEMMs with rows stationary in registers, the K-split
     down projection, the MFMA prompt attention, a second KV block) run the same check through the prompt path; with
     `weights="fp8"` the engine stores the layer GEMM weights as e4m3 with a power-of-two row scale and the oracle runs
-    on exactly those dequantised weights, so the same bounds apply (the quantisation itself is not judged here)."""
+    on exactly those dequantised weights, so the same bounds apply (the quantisation itself is not judged here).
+    Eight streams are the benchmark's batch (one 16-row tile, half of it streams); twelve use the 16-row graphs with
+    every MFMA column a row of its own and four rows idle."""
     from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
     monkeypatch.setenv("QTTS_WEIGHT_DTYPE", weights)
     cfg = synthetic.make_config(size)
@@ -301,12 +305,12 @@ def test_full_size_frames_match_oracle(size, weights, prompt_lens, tmp_path, mon
     tw, pw = synthetic.split_state_dict(sd)
     del sd
     json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
-    H, S, NF = cfg["talker_config"]["hidden_size"], 2, 3
+    H, S, NF = cfg["talker_config"]["hidden_size"], len(prompt_lens), 3
     gen = torch.Generator().manual_seed(17)
     prompts = [torch.randn(L, H, generator=gen) * 0.5 for L in prompt_lens]
     text_adds = torch.randn(S, NF, H, generator=gen) * 0.3
     fe = FrameEngine(str(tmp_path), max_streams=S, max_text_frames=NF + 1, talker_weights=tw, predictor_weights=pw,
-                     num_kvcache_blocks=4, max_num_batched_tokens=1024, codec_eos=None)
+                     num_kvcache_blocks=max(4, S), max_num_batched_tokens=1024, codec_eos=None)
     t_logits, p_logits = [[] for _ in range(S)], []
     for i in range(S):
         fe.add_stream(prompts[i], text_adds[i], max_frames=NF, talker_sampling=greedy_sp(1), predictor_sampling=greedy_sp(17))
