@@ -9,10 +9,13 @@ rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 step() { echo "== $1" >&2; }
 
-step bench
-timeout -k 10 400 python3 -u $R/bench.py --steps 100 --warmup 10 > $O/bench_line.json 2> $O/bench.err
 step bench-trace
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_line_profiled.json 2> $O/trace.err
+# the bench line quotes the profiler's figure for its dominant kernel from profiles/: put this trace's summary there first
+rm -f $R/profiles/r02_bench_summary_*.txt
+python3 $R/tools/profile_summary.py $O/trace/vm $R/profiles/r02_bench_summary_${1:-v1}.txt "same box, same build" > /dev/null
+step bench
+timeout -k 10 400 python3 -u $R/bench.py --steps 100 --warmup 10 > $O/bench_line.json 2> $O/bench.err
 step pmc-fetch
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/tools/microbench.py dominant >> $O/prof.log 2>&1
 step pmc-write
