@@ -223,6 +223,8 @@ static int g_rows_min = 32;              // most rows that still take single-til
 static int g_share_prologue = 1;         // norm prologue shared between the lane halves for up to 8 rows (0: tuning)
 static int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
 static int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention takes the MFMA kernel for prompts
+static int g_rows_tm = 0;                // row tiles per workgroup of the prompt GEMM (0 = chosen per shape)
+extern "C" void qtts_tune_rows_tm(int tm) { g_rows_tm = tm; }
 extern "C" void qtts_tune_linear(int ksw, int t) { g_tune_ksw = ksw; g_tune_t = t; }
 extern "C" void qtts_tune_subtiles(int min_bytes) { g_sub_min_bytes = min_bytes; }
 extern "C" void qtts_tune_rows(int min_rows) { g_rows_min = min_rows; }
@@ -238,6 +240,7 @@ static constexpr int g_rows_min = 32;              // most rows that still take 
 static constexpr int g_share_prologue = 1;         // norm prologue shared between the lane halves for up to 8 rows
 static constexpr int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
 static constexpr int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention takes the MFMA kernel for prompts
+static constexpr int g_rows_tm = 0;                // row tiles per workgroup of the prompt GEMM (0 = chosen per shape)
 #endif
 
 // ------------------------------------------------------------------ linear (skinny GEMM on MFMA)
@@ -1070,7 +1073,39 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     if (ksw == 12 && silu_pairs) return false;
     if (a.bias && kparts == 1) return false;              // the single-pass epilogue carries no bias
     const int mtiles = (a.M + 15) / 16;
-    const int TM = (mtiles <= 2 || ksw == 12) ? 2 : 4;
+    const int ntiles = a.N / 16;
+    // Row tiles per workgroup (TM).  More row tiles per workgroup mean fewer passes over the weights (fewer, longer
+    // column blocks in the one round of workgroups) but more activation tiles to pull in before the first
+    // multiplication, and those are the expensive ones: every workgroup of an XCD asks its L2 for the same rows at the
+    // same moment, nothing is multiplied until they are there, and they hold the registers the weight stream could
+    // use.  Measured on the talker's four GEMMs at 40..400 rows (activations in fragment order) with TM forced to
+    // 2 / 3 / 4: a row tile costs a workgroup about what two weight tiles do (qkv at 96 rows: 9.6 us with four row
+    // tiles, 8.0 with three; gate/up at 48 rows 15.1 -> 13.0 with three, at 200 rows 22.6 with four against 30.4 with
+    // two; o_proj is fastest with two up to 256 rows).  The plan with the lowest 2 * TM + weight tiles wins; ties go
+    // to the larger TM (fewer re-reads of the weights from L2).  The K-split form takes two or four (three measured
+    // 2-3 us slower at 64..96 rows with the same tiles per workgroup).
+    auto plan = [&](int tm, int *tpw_out) {
+        const int rg = (mtiles + tm - 1) / tm;
+        const int gxm = 8 * std::max(1, 32 / (rg * kparts));
+        const int tpw_ = (ntiles + gxm - 1) / gxm;
+        if (tpw_out) *tpw_out = tpw_;
+        // (row groups x K parts beyond the 32 CUs of an XCD: the launch takes several rounds of workgroups)
+        const int gx_ = (ntiles + tpw_ - 1) / tpw_;
+        const int rounds = (rg * kparts * ((gx_ + 7) / 8) + 31) / 32;
+        return rounds * (4 * tm + (a.wscale ? tpw_ : 2 * tpw_));
+    };
+    int TM = 2;
+    if (ksw != 12) {
+        const int cands[] = {4, 3, 2};
+        int best = 1 << 30;
+        for (int tm : cands) {
+            if (tm == 3 && (ksw != 8 || kparts > 1)) continue;   // three row tiles: built for K = 2048 in one part
+            if (tm > 2 && mtiles <= 2) continue;
+            const int c = plan(tm, nullptr);
+            if (c < best) { best = c; TM = tm; }
+        }
+    }
+    if (g_rows_tm == 2 || (g_rows_tm == 4 && ksw != 12 && mtiles > 2) || (g_rows_tm == 3 && ksw == 8 && kparts == 1 && mtiles > 2)) TM = g_rows_tm;
     RowsArgs r;
     r.bias = a.bias; r.res = a.res; r.ldr = a.ldr; r.out = a.out; r.ldo = a.ldo;
     r.part = scratch; r.mpad = a.M; r.rgroups = (mtiles + TM - 1) / TM; r.KS = KS;
@@ -1079,7 +1114,6 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
 #endif
     r.wscale = a.wscale;
     r.xpacked = (g_dbg_linear & 64) != 0 ? 1 : a.xpacked; r.opks = a.opks; r.xnpks = a.nnpks;   // (bit 6: timing experiments read x in fragment order)
-    const int ntiles = a.N / 16;
     // One round of workgroups (a CU holds one, an XCD 32): workgroup i runs on XCD i % 8 and the launch is laid out
     // in groups of 8 column blocks x all row groups (x K parts), so the groups of 8 that fit one round are
     // 32 / (row groups x K parts); each workgroup streams `tpw` weight tiles.
@@ -1093,6 +1127,7 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     if (ksw == 12) QR(12, 2, 0);
     else if (ksw == 8) {
         if (TM == 2) { if (epi == 0) QR(8, 2, 0); else if (epi == 1) QR(8, 2, 1); else QR(8, 2, 2); }
+        else if (TM == 3) { if (epi == 0) QR(8, 3, 0); else QR(8, 3, 1); }
         else { if (epi == 0) QR(8, 4, 0); else if (epi == 1) QR(8, 4, 1); else QR(8, 4, 2); }
     } else {
         if (TM == 2) { if (epi == 0) QR(4, 2, 0); else QR(4, 2, 1); }

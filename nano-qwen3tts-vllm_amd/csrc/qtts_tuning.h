@@ -15,6 +15,7 @@ extern "C" {
 void qtts_tune_linear(int ksw, int tiles_per_cu);   /* k-steps per wave / workgroups per CU of the decode GEMM; 0 = automatic */
 void qtts_tune_subtiles(int min_bytes);             /* smallest weight slice of a workgroup that shares a tile */
 void qtts_tune_rows(int min_rows);                  /* most rows that still take single-tile workgroups */
+void qtts_tune_rows_tm(int tm);                     /* row tiles per workgroup of the prompt GEMM (2, 3, 4); 0 = per shape */
 void qtts_tune_shared_prologue(int on);             /* lane halves share the activation prologue (<= 8 rows) */
 void qtts_tune_prompt_attention(int min_rows);      /* rows from which prompts take the MFMA attention kernel */
 void qtts_debug_linear(int flags);                  /* bit 0: every tile reads weight tile 0; bit 1: no prompt GEMM; bit 5: no fused norm */

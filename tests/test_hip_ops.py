@@ -391,7 +391,10 @@ def test_attention_decode_fused(hip, Hq, Hkv, ctxs):
                                         (20, 2048, 2048, "plain"), (32, 6144, 1024, "swiglu_plain"), (64, 1024, 1024, "res"),
                                         (200, 2048, 6144, "ws_res"), (35, 2048, 6144, "ws_bias"), (100, 1024, 3072, "ws_res"),
                                         (1000, 2048, 2048, "res"), (24, 4096, 2048, "norm"), (32, 12288, 2048, "swiglu"),
-                                        (64, 4096, 1024, "norm"), (130, 6144, 1024, "swiglu"), (20, 1024, 1024, "norm")])
+                                        (64, 4096, 1024, "norm"), (130, 6144, 1024, "swiglu"), (20, 1024, 1024, "norm"),
+                                        # row groups of three tiles (K = 2048, 3 / 6 / 9 row tiles) and of two (narrow outputs)
+                                        (90, 4096, 2048, "res"), (44, 12288, 2048, "swiglu_plain"), (140, 12288, 2048, "swiglu_plain"),
+                                        (48, 2048, 2048, "res"), (130, 2048, 2048, "res")])
 def test_linear_prefill_row_counts(hip, M, N, K, kind):
     """Prefill-sized row counts (several 16-row tiles, ragged last tile) through every GEMM variant of the
     decoder stack, against the oracle."""
@@ -492,7 +495,8 @@ def test_fp8_pack_matches_torch_quantisation(hip):
                                         (200, 4096, 2048, "plain"), (40, 2048, 2048, "res"), (200, 2048, 6144, "res"),
                                         (130, 1024, 3072, "bias"), (200, 6144, 2048, "swiglu_plain"), (32, 6144, 1024, "swiglu_plain"),
                                         (128, 12288, 2048, "swiglu_plain"), (24, 4096, 2048, "norm"), (100, 6144, 1024, "swiglu"),
-                                        (64, 4096, 1024, "norm")])
+                                        (64, 4096, 1024, "norm"), (90, 4096, 2048, "res"), (44, 12288, 2048, "swiglu_plain"),
+                                        (140, 12288, 2048, "swiglu_plain"), (300, 4096, 2048, "res")])
 def test_linear_fp8_equals_bf16_on_dequantised_weights(hip, M, N, K, kind):
     """Every GEMM variant over fp8 weights returns bit for bit what the bf16 kernel returns on the dequantised
     weights q * scale (which are bf16 numbers), and the dequantised weights are the oracle's."""
@@ -525,10 +529,11 @@ def test_linear_fp8_equals_bf16_on_dequantised_weights(hip, M, N, K, kind):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("M,N,K", [(33, 2048, 2048), (48, 4096, 1024), (40, 1024, 3072), (64, 2048, 6144), (100, 1024, 3072)])
+@pytest.mark.parametrize("M,N,K", [(33, 2048, 2048), (48, 4096, 1024), (40, 1024, 3072), (64, 2048, 6144), (100, 1024, 3072),
+                                   (96, 4096, 2048), (200, 4096, 2048), (600, 2048, 6144)])
 def test_prompt_gemm_row_group_forms(hip, M, N, K):
-    """From 33 rows a GEMM takes the prompt kernel: row groups of four 16-row tiles, of two for K = 3072 (twelve
-    k-steps per wave), K = 6144 as K parts through the workspace; partial last tiles and groups."""
+    """From 33 rows a GEMM takes the prompt kernel: row groups of two, three or four 16-row tiles (chosen per shape; two
+    for K = 3072, twelve k-steps per wave), K = 6144 as K parts through the workspace; partial last tiles and groups."""
     g = torch.Generator().manual_seed(M * N + K)
     x = torch.randn(M, K, generator=g).bfloat16()
     w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()

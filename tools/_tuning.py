@@ -23,6 +23,7 @@ for _name, (_res, _args) in {
     "qtts_tune_subtiles": (None, [_i]),
     "qtts_tune_prompt_attention": (None, [_i]),
     "qtts_tune_rows": (None, [_i]),
+    "qtts_tune_rows_tm": (None, [_i]),
     "qtts_tune_shared_prologue": (None, [_i]),
     "qtts_debug_linear": (None, [_i]),
     "qtts_debug_linear_trace": (None, [_p]),

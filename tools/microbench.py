@@ -306,6 +306,7 @@ def rows():
     H, I = 2048, 6144
     nl = 28
     hip.lib.qtts_debug_linear(int(os.environ.get("QTTS_LINEAR_DBG", "0")))
+    hip.lib.qtts_tune_rows_tm(int(os.environ.get("QTTS_ROWS_TM", "0")))
     shapes = [("qkv", 4096, H, "plain"), ("o_proj", H, H, "res"), ("gate_up", 2 * I, H, "swiglu"), ("down", H, I, "ws")]
     only = os.environ.get("QTTS_ROWS_ONLY")
     for name, N, K, kind in shapes:
@@ -431,6 +432,7 @@ def prefill():
                      num_kvcache_blocks=8, max_num_batched_tokens=4096, codec_eos=None)
     sp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
     hip.lib.qtts_debug_linear(int(os.environ.get("QTTS_LINEAR_DBG", "0")))
+    hip.lib.qtts_tune_rows_tm(int(os.environ.get("QTTS_ROWS_TM", "0")))
     if os.environ.get("QTTS_MFMA_ATTN_ROWS"):
         hip.lib.qtts_tune_prompt_attention(int(os.environ["QTTS_MFMA_ATTN_ROWS"]))
     for plen in [int(v) for v in os.environ.get("QTTS_FRAME_PROMPT", "200").split(",")]:
