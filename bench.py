@@ -241,11 +241,22 @@ def percentile(xs, q):
     return xs[min(len(xs) - 1, int(round(q * (len(xs) - 1))))] if xs else None
 
 
-def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed, overlap=False):
+ADMISSION_MODES = {
+    "serial": "prefill between two frames",
+    "beside": "prefill on a second stream beside the running frames, joined once finished",
+    "join": "prefill started on a second stream as soon as the request arrives, beside the frame in flight; the next frame waits for it",
+}
+
+
+def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed, admission="join"):
     """BASELINE.json configs[2] as a serving workload: `streams` requests arrive `gap_s` apart (prompt lengths cycling
-    through `lens`), each wants `frames` frames; admission and prefill happen inside the timed region, between two
-    frames of the running batch, as a server's loop does.  Returns throughput and latency statistics; the clock is
-    the host's (a frame is counted when its 16 codes are on the host)."""
+    through `lens`), each wants `frames` frames; admission and prefill happen inside the timed region, as in a
+    server's loop.  admission "serial": what has arrived is admitted between two frames, its packed prefill runs there.
+    "join" / "beside": arrivals are also looked for while the host waits for a frame's codes, and their packed prefill
+    starts at once on a second stream (FrameEngine.add_streams(wait=False)); the newcomers join with the next frame
+    ("join": it waits for the rest of the prefill) or with the first frame after the prefill has finished ("beside").
+    Returns throughput and latency statistics; the clock is the host's (a frame is counted when its 16 codes are on the
+    host)."""
     from nano_qwen3tts_vllm.engine.frame_engine import NoCapacity
     g = torch.Generator().manual_seed(seed)
     reqs = []
@@ -255,25 +266,22 @@ def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed, ov
     torch.cuda.synchronize()
     arrival = [i * gap_s for i in range(streams)]
     first, last, gaps, done_frames, sid_of = {}, {}, [], {}, {}
-    nxt = 0
+    state = {"nxt": 0}
+    detached = admission != "serial"
+    fe.join_prefills = admission == "join"
     t0 = time.perf_counter()
     now = lambda: time.perf_counter() - t0
-    while len(done_frames) < streams or fe.streams:
+
+    def admit():
+        """Everything that has arrived by now goes to the engine in one call (one packed prefill), as a serving loop does."""
+        nxt = state["nxt"]
         due = []
         while nxt + len(due) < streams and now() >= arrival[nxt + len(due)] and len(fe.streams) + len(due) < fe.max_streams:
             due.append(nxt + len(due))
-        if due and not overlap:
-            # everything that has arrived by now goes to the engine in one call (one packed prefill), as the serving loop does
-            res = fe.add_streams([dict(prompt_embeds=reqs[i][1], text_adds=reqs[i][2], max_frames=frames, talker_sampling=samplers[0],
-                                       predictor_sampling=samplers[1], sid=f"arr-{i}") for i in due])
-        else:
-            res = []
-            for i in due:
-                try:
-                    res.append(fe.add_stream(reqs[i][1], reqs[i][2], max_frames=frames, talker_sampling=samplers[0],
-                                             predictor_sampling=samplers[1], sid=f"arr-{i}", wait=False))
-                except NoCapacity as e:
-                    res.append(e)
+        if not due:
+            return
+        res = fe.add_streams([dict(prompt_embeds=reqs[i][1], text_adds=reqs[i][2], max_frames=frames, talker_sampling=samplers[0],
+                                   predictor_sampling=samplers[1], sid=f"arr-{i}") for i in due], wait=not detached)
         for i, r in zip(due, res):
             if isinstance(r, Exception):
                 if isinstance(r, NoCapacity):
@@ -281,13 +289,16 @@ def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed, ov
                 raise r
             sid_of[r] = i
             done_frames[i] = 0
-            nxt += 1
+            state["nxt"] += 1
+
+    while len(done_frames) < streams or fe.streams:
+        admit()
         if not fe.streams:
-            if nxt >= streams:
+            if state["nxt"] >= streams:
                 break
-            time.sleep(max(0.0, min(arrival[nxt] - now(), 0.001)))
+            time.sleep(max(0.0, min(arrival[state["nxt"]] - now(), 0.001)))
             continue
-        res = fe.step()
+        res = fe.step(poll=admit if detached else None)
         t = now()
         for sid in res:
             i = sid_of[sid]
@@ -306,7 +317,7 @@ def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed, ov
             "rtf_per_stream_mean": statistics.fmean((last[i] - arrival[i]) / (frames * FRAME_SECONDS) for i in range(streams)),
             "first_chunk_ms_p50": ms(percentile(list(first.values()), 0.5)), "first_chunk_ms_p99": ms(percentile(list(first.values()), 0.99)),
             "inter_chunk_ms_p50": ms(percentile(gaps, 0.5)), "inter_chunk_ms_p99": ms(percentile(gaps, 0.99)),
-            "admission": "prefill on a second stream beside the running frames" if overlap else "prefill between two frames",
+            "admission": ADMISSION_MODES[admission],
             "note": "prefill and admission inside the timed region; first chunk = arrival -> the stream's first 16-code frame on the host"}
 
 
@@ -387,7 +398,8 @@ def main():
     # by rank 0 at N = 1 beside the contract number)
     arrivals = None
     if not args.no_arrivals and world == 1:
-        overlap = os.environ.get("QTTS_OVERLAP_PREFILL", "0") == "1"
+        overlap = os.environ.get("QTTS_ADMISSION", "join")
+        assert overlap in ADMISSION_MODES, overlap
         run_arrivals(fe, device, H, 2, 3, 0.0, lens, (greedy_t, greedy_p), 1999, overlap)      # (first use of the second stream)
         arrivals = run_arrivals(fe, device, H, B, ARRIVAL_FRAMES, ARRIVAL_GAP_S, lens, (greedy_t, greedy_p), 2000 + rank, overlap)
         assert not fe.streams

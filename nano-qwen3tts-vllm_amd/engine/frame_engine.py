@@ -18,7 +18,9 @@ work for embedding-fed sequences.
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import time
 
 import torch
 
@@ -45,6 +47,11 @@ class Stream:
 
 class FrameEngine:
     overlapped_admission = True       # add_stream(wait=False) prefills beside the running frames
+    # When a stream whose prompt is prefilled beside the frames joins the batch.  True: with the next frame - the
+    # engine's stream waits for the rest of the prefill (the running streams' frame is late by what is left of it, the
+    # newcomer has its first frame as early as it can).  False: with the first frame that starts after the prefill has
+    # finished (the running streams never wait; the newcomer may lose most of a frame).
+    join_prefills = True
 
     def __init__(self, model_dir: str, max_streams: int = 8, max_text_frames: int = 1024, talker_weights=None,
                  predictor_weights=None, enforce_eager: bool = False, codec_eos: int | None = CODEC_EOS, top_k: int = 50,
@@ -89,10 +96,18 @@ class FrameEngine:
         # stream is switched on between two frames: the frame graphs rewrite cur_hidden / cur_token of every row
         self.pend_hidden = torch.zeros(max_streams, H, dtype=torch.bfloat16, device=dev)
         self.pend_token = torch.zeros(max_streams, dtype=torch.int64, device=dev)
-        self._pre_temp = torch.ones(1, dtype=torch.float32, device=dev)
+        self._pre_hidden = torch.zeros(max_streams, H, dtype=torch.bfloat16, device=dev)
+        self._pre_token = torch.zeros(max_streams, dtype=torch.int64, device=dev)
+        self._pre_drawn = torch.zeros(max_streams, dtype=torch.int64, device=dev)
+        self._pre_temps = torch.ones(max_streams, dtype=torch.float32, device=dev)
         self.pre_stream = torch.cuda.Stream(device=dev)          # prefill beside the frames
-        self._prefill_running: Stream | None = None               # at most one detached prefill in flight
-        self._prefill_waiting: list = []                          # (stream, sampling) admitted, prefill not started yet
+        self._prefill_running: list | None = None                 # the streams of the one detached prefill in flight
+        self._prefill_waiting: list = []                          # groups of streams admitted, prefill not started yet
+        # a detached prefill is ordered behind this event of the engine's stream, not behind everything queued there:
+        # it marks the last moment KV blocks or rows were handed back (a finished stream's last talker step may still
+        # be writing its blocks) and the end of the last prefill that ran between two frames
+        self._fence = torch.cuda.Event()
+        self._fence.record(self.tr.stream)
         self.rows: list[Stream | None] = [None] * max_streams
         self.streams: dict[str, Stream] = {}
         self.graphs: dict[tuple, hip.Graph] = {}            # talker part, per (batch bucket, context bucket)
@@ -119,8 +134,8 @@ class FrameEngine:
         frame f (trailing text hiddens, then the tts pad embedding; the last row repeats).
         wait=True: the prompt is prefilled before this returns and the stream takes part in the next frame.
         wait=False (serving loops): the row and the KV blocks are reserved and the call returns; the prefill runs on a
-        second HIP stream BESIDE the frames of the running streams instead of between two of them, and the stream
-        joins the batch at the first frame boundary after it has finished (one prefill at a time, in arrival order).
+        second HIP stream BESIDE the frames of the running streams instead of between two of them; when the stream
+        joins the batch is the engine's `join_prefills` policy (see step).  One prefill at a time, in arrival order.
         Same launches, same ids either way.
         Raises NoCapacity (no free row / KV blocks now: try again when a stream has ended) or ValueError (can never
         be served: too long, wrong shapes, a top_k the graphs were not captured for)."""
@@ -128,20 +143,17 @@ class FrameEngine:
         if wait:
             self._prefill_now([s])
         else:
-            with self.tr.on_stream():
-                self._write_row(s)
-            s.active = False
-            self._prefill_waiting.append((s, s.tsp))
-            self._pump_prefills()
+            self._prefill_detached([s])
         return s.sid
 
-    def add_streams(self, requests: list[dict]) -> list:
+    def add_streams(self, requests: list[dict], wait: bool = True) -> list:
         """Admits several requests at once (dicts of add_stream's arguments, without `wait`): their prompts are
-        packed into ONE prefill (all rows of all prompts through each GEMM together — the reference's scheduler packs
+        packed into ONE prefill (all rows of all prompts through each GEMM together - the reference's scheduler packs
         the prompts that arrive within its collection window the same way, P/engine/scheduler.py:31-56), which costs
-        about half of prefilling them one after the other.  Returns, per request and in order, the stream id or the
-        exception (NoCapacity / ValueError) that add_stream would have raised; the ids a stream then produces do not
-        depend on what it was packed with."""
+        about half of prefilling them one after the other.  wait=False: that packed prefill runs beside the frames, as
+        add_stream(wait=False).  Returns, per request and in order, the stream id or the exception (NoCapacity /
+        ValueError) that add_stream would have raised; the ids a stream then produces do not depend on what it was
+        packed with."""
         out, fresh = [], []
         for r in requests:
             try:
@@ -151,9 +163,39 @@ class FrameEngine:
                 out.append(s.sid)
             except (NoCapacity, ValueError) as e:
                 out.append(e)
-        if fresh:
+        if fresh and wait:
             self._prefill_now(fresh)
+        elif fresh:
+            self._prefill_detached(fresh)
         return out
+
+    def _prefill_detached(self, streams: list[Stream]):
+        """Queues the packed prefill of freshly reserved streams for the second HIP stream (groups within the
+        runner's row limit) and starts it if none is running."""
+        groups, rows = [[]], 0
+        for s in streams:
+            if groups[-1] and rows + s.prompt_len > self.tr.max_rows:
+                groups.append([])
+                rows = 0
+            groups[-1].append(s)
+            rows += s.prompt_len
+        with self._on_engine_stream():
+            for s in streams:
+                self._write_row(s)
+                s.active = False
+        self._prefill_waiting.extend(groups)
+        self._pump_prefills()
+
+    @contextlib.contextmanager
+    def _on_engine_stream(self):
+        """The engine's stream made current, ordered after the caller's stream - but, unlike ModelRunner.on_stream, the
+        caller's stream is NOT made to wait for the engine's afterwards: what is enqueued here is consumed on the
+        engine's stream only, and a caller's stream that waited for every frame queued there could no longer feed a
+        prefill that is meant to run beside those frames."""
+        outer = torch.cuda.current_stream(self.device)
+        self.tr.stream.wait_stream(outer)
+        with torch.cuda.stream(self.tr.stream):
+            yield
 
     def _reserve(self, prompt_embeds, text_adds, max_frames, talker_sampling, predictor_sampling, sid) -> Stream:
         """Checks the request, takes a row and the KV blocks of the stream's whole lifetime."""
@@ -233,55 +275,69 @@ class FrameEngine:
                     self.cur_hidden[s.row].copy_(hidden[i])
                     self.cur_token[s.row] = toks[i]
                     self._sync_row_to_device(s.row)
+            self._fence.record(self.tr.stream)
 
     # ---------------------------------------------------------------- prefill beside the frames
-    def _start_prefill(self, s: Stream, tsp: SamplingParams):
+    def _start_prefill(self, group: list[Stream]):
         tr = self.tr
-        self.pre_stream.wait_stream(torch.cuda.current_stream(self.device))      # the prompt's producer
-        self.pre_stream.wait_stream(tr.stream)                                   # the row's earlier tenant has left
+        self.pre_stream.wait_stream(torch.cuda.current_stream(self.device))      # the prompts' producer
+        self.pre_stream.wait_event(self._fence)            # the blocks' and rows' earlier tenants have left
         with torch.cuda.stream(self.pre_stream):
-            tr.prefill_detached(s.seq, self.pend_hidden[s.row], self.pend_token[s.row:s.row + 1])
-            s.seq.append_token(-1, None)                  # the first code itself stays on the device (pend_token)
-            if tsp.do_sample:
-                self._pre_temp.fill_(tsp.temperature)
-                hip.check(hip.lib.qtts_sample_topk(hip.ptr(tr.pre_logits), tr.vocab, hip.ptr(self._pre_temp), self.top_k,
+            # (no host-built index tensors here: their upload would make the host wait for this stream)
+            n = len(group)
+            tr.prefill_detached([s.seq for s in group], self._pre_hidden[:n], self._pre_token[:n])
+            if any(s.tsp.do_sample for s in group):
+                # rows that sample draw their first code from their logits row (the arg-max rows keep theirs)
+                for i, s in enumerate(group):
+                    self._pre_temps[i] = s.tsp.temperature
+                hip.check(hip.lib.qtts_sample_topk(hip.ptr(tr.pre_logits), tr.vocab, hip.ptr(self._pre_temps), self.top_k,
                                                    tr.rng_seed, tr.next_rng_offset() + (1 << 40),
-                                                   hip.ptr(self.pend_token[s.row:s.row + 1]), 1, tr.vocab, hip.stream()),
+                                                   hip.ptr(self._pre_drawn), n, tr.vocab, hip.stream()),
                           "sample_topk")
-            s.ready = torch.cuda.Event()
-            s.ready.record(self.pre_stream)
-        self._prefill_running = s
+            for i, s in enumerate(group):
+                self.pend_hidden[s.row].copy_(self._pre_hidden[i], non_blocking=True)
+                src = self._pre_drawn if s.tsp.do_sample else self._pre_token
+                self.pend_token[s.row:s.row + 1].copy_(src[i:i + 1], non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.pre_stream)
+        for s in group:
+            s.seq.append_token(-1, None)                  # the first code itself stays on the device (pend_token)
+            s.ready = ready
+        self._prefill_running = group
 
     def _pump_prefills(self, block: bool = False):
-        """Switches a stream on once its prefill has finished (between two frames: called by step / run_frames before
-        they launch) and starts the next waiting prefill.  block: wait for the running prefill (nothing else to do)."""
+        """Switches streams on once their prefill has finished (between two frames: called by step / run_frames before
+        they launch) and starts the next waiting prefill.  block: do not ask whether the running prefill has finished
+        but make the engine's stream wait for it (the host does not wait)."""
         while True:
-            s = self._prefill_running
-            if s is not None:
-                if s.sid not in self.streams or self.streams[s.sid] is not s:      # cancelled meanwhile
-                    s.ready.synchronize()
+            group = self._prefill_running
+            if group is not None:
+                ready = group[0].ready
+                live = [s for s in group if self.streams.get(s.sid) is s]       # (the others were cancelled meanwhile)
+                if not live:
+                    ready.synchronize()
                     self._prefill_running = None
                     continue
-                if not (block or s.ready.query()):
+                if not (block or ready.query()):
                     return
-                with self.tr.on_stream():
-                    self.tr.stream.wait_event(s.ready)
-                    self.cur_hidden[s.row].copy_(self.pend_hidden[s.row], non_blocking=True)
-                    self.cur_token[s.row:s.row + 1].copy_(self.pend_token[s.row:s.row + 1], non_blocking=True)
-                    self._sync_row_to_device(s.row)
-                s.active = True
+                with self._on_engine_stream():
+                    self.tr.stream.wait_event(ready)
+                    for s in live:
+                        self.cur_hidden[s.row].copy_(self.pend_hidden[s.row], non_blocking=True)
+                        self.cur_token[s.row:s.row + 1].copy_(self.pend_token[s.row:s.row + 1], non_blocking=True)
+                        self._sync_row_to_device(s.row)
+                        s.active = True
                 self._prefill_running = None
                 block = False
-            self._prefill_waiting = [(w, sp) for w, sp in self._prefill_waiting if self.streams.get(w.sid) is w]
+            self._prefill_waiting = [g for g in ([s for s in grp if self.streams.get(s.sid) is s] for grp in self._prefill_waiting) if g]
             if not self._prefill_waiting:
                 return
-            nxt, sp = self._prefill_waiting.pop(0)
-            self._start_prefill(nxt, sp)
+            self._start_prefill(self._prefill_waiting.pop(0))
 
     def _activate_or_wait(self) -> bool:
         """Before a frame: admit what is ready; when no stream is active yet but prefills are under way, wait for the
         first.  Returns whether any stream is active."""
-        self._pump_prefills()
+        self._pump_prefills(block=self.join_prefills)
         while not any(s.active for s in self.streams.values()):
             if self._prefill_running is None and not self._prefill_waiting:
                 return False
@@ -298,16 +354,16 @@ class FrameEngine:
         s = self.streams.pop(sid, None)
         if s is None:
             return
-        if self._prefill_running is s:               # its prefill still writes the KV blocks that are about to be freed
-            s.ready.synchronize()
-            self._prefill_running = None
-        self._prefill_waiting = [(w, sp) for w, sp in self._prefill_waiting if w is not s]
+        if self._prefill_running is not None and s in self._prefill_running:
+            s.ready.synchronize()                    # its prefill still writes the KV blocks that are about to be freed
+        self._prefill_waiting = [g for g in ([w for w in grp if w is not s] for grp in self._prefill_waiting) if g]
         self.rows[s.row] = None
         st = self.tr.dstage
-        with self.tr.on_stream():
+        with self._on_engine_stream():
             st.h("ctx")[s.row] = 0
             st.h("slots")[s.row] = -1
             self._sync_row_to_device(s.row)
+            self._fence.record(self.tr.stream)       # whoever gets the row or the blocks next starts behind this
         self.talker.scheduler.block_manager.deallocate(s.seq)
 
     # ---------------------------------------------------------------- the frame
@@ -447,14 +503,18 @@ class FrameEngine:
                 s.frames.extend(out[:, s.row].tolist())
         return out
 
-    def step(self) -> dict[str, list[int]]:
+    def step(self, poll=None) -> dict[str, list[int]]:
         """One frame for every active stream; streams whose talker id is the codec EOS finish
         without yielding that frame (as P/interface.py:1233-1239); a stream that has produced its max_frames
-        finishes with that frame (the explicit length guard the reference lacks)."""
+        finishes with that frame (the explicit length guard the reference lacks).
+        poll: called (with no arguments; at least once, then every 50 us or so) while the host waits for the frame's codes; a serving loop
+        admits what has arrived meanwhile from it with add_stream(s)(wait=False), so a prompt's prefill starts beside
+        the frame in flight instead of after the next time the loop gets round to looking."""
         if not self.streams or not self._activate_or_wait():
             return {}
         bs = self._bucket()
-        with self.tr.on_stream():
+        live = [s for s in self.streams.values() if s.active]      # (poll may admit and even switch on others meanwhile)
+        with self._on_engine_stream():
             self._setup_predictor_meta(bs)
             # the frame's codes are final once the predictor burst is done: they travel to the host while the talker
             # step that starts the next frame is already running (the reference yields before that step too,
@@ -463,11 +523,18 @@ class FrameEngine:
             self._codes_host[:bs].copy_(self.codes[:bs], non_blocking=True)
             self._codes_event.record(torch.cuda.current_stream())
             self._launch_talker(bs, self._max_ctx_bucket())
+        if poll is None:
             self._codes_event.synchronize()
-            codes = self._codes_host[:bs].tolist()
+        else:
+            while True:
+                poll()
+                if self._codes_event.query():
+                    break
+                time.sleep(5e-5)
+        codes = self._codes_host[:bs].tolist()
         res = {}
-        for s in list(self.streams.values()):
-            if not s.active:
+        for s in live:
+            if self.streams.get(s.sid) is not s:
                 continue
             c = codes[s.row]
             if self.codec_eos is not None and c[0] == self.codec_eos:

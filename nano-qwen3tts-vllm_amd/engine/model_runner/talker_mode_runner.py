@@ -69,11 +69,11 @@ class TalkerModeModelRunner(ModelRunner):
         hip.check(hip.lib.qtts_argmax(hip.ptr(self.logits), self.vocab, hip.ptr(self.tokens), bs, self.vocab,
                                       hip.stream()), "argmax")
 
-    def _fill_inputs(self, embeds: list[torch.Tensor], n_rows: int):
+    def _fill_inputs(self, embeds: list[torch.Tensor], n_rows: int, x_buf: torch.Tensor | None = None):
         rows = [e.reshape(-1, e.shape[-1]) for e in embeds]
         x = torch.cat(rows, 0) if len(rows) > 1 else rows[0]
         assert x.shape[0] == n_rows
-        self.x_buf[:n_rows].copy_(x.to(torch.bfloat16), non_blocking=True)
+        (self.x_buf if x_buf is None else x_buf)[:n_rows].copy_(x.to(torch.bfloat16), non_blocking=True)
 
     def _pick(self, seqs: list[Sequence], S: int) -> list[int]:
         """Greedy ids are already in self.tokens; draw for the rows that sample."""
@@ -87,11 +87,11 @@ class TalkerModeModelRunner(ModelRunner):
         return self.tokens[:S].tolist()
 
     # ---- reference-shaped entry points ---------------------------------------------
-    def prepare_prefill(self, seqs: list[Sequence]):
+    def prepare_prefill(self, seqs: list[Sequence], stage: Staging | None = None, x_buf: torch.Tensor | None = None):
         positions, slots, row_seq, ctx, cu = self.prefill_metadata(seqs, self.block_size)
         N, S, mb = len(positions), len(seqs), self.max_blocks_per_seq
         assert N <= self.max_rows and S <= self.max_bs
-        st = self.pstage
+        st = stage or self.pstage
         st.h("positions")[:N] = torch.tensor(positions, dtype=torch.int64)
         st.h("slots")[:N] = torch.tensor(slots, dtype=torch.int32)
         st.h("ctx")[:N] = torch.tensor(ctx, dtype=torch.int32)
@@ -101,7 +101,7 @@ class TalkerModeModelRunner(ModelRunner):
         for i, s in enumerate(seqs):
             tab[i, :len(s.block_table)] = torch.tensor(s.block_table, dtype=torch.int32)
         st.upload()
-        self._fill_inputs([s.input_embeds for s in seqs], N)
+        self._fill_inputs([s.input_embeds for s in seqs], N, x_buf)
         return N, S, cu, max(len(s) for s in seqs)
 
     def prepare_decode_talker(self, seqs: list[Sequence], bs: int):
@@ -160,25 +160,40 @@ class TalkerModeModelRunner(ModelRunner):
         token_ids = self._pick(seqs, S)
         return token_ids, hidden
 
-    # ---- a prompt's prefill next to running decode steps -------------------------------
-    def prefill_detached(self, seq: Sequence, hidden_out: torch.Tensor, token_out: torch.Tensor):
-        """The prefill of `run([seq], True)` for one sequence, enqueued on the CURRENT stream without any host
-        synchronisation and without touching what the decode steps use: it runs through a twin of the decoder (own
-        workspace) and its own logits row, and leaves the last position's post-norm hidden state in hidden_out [H]
-        and the first code in token_out [1] (int64; arg-max — a sampling request draws its first code from
-        `self.pre_logits` by the caller).  One such prefill may be in flight at a time (the metadata staging buffer
-        is reused).  Same launches, same arithmetic as the synchronous path."""
+    # ---- prompts prefilled next to running decode steps --------------------------------
+    def prefill_detached(self, seqs, hidden_out: torch.Tensor, token_out: torch.Tensor):
+        """The prefill of `run(seqs, True)` (one sequence or a list, packed), enqueued on the CURRENT stream without
+        any host synchronisation and without touching what the decode steps or the synchronous prefill use: it runs
+        through a twin of the decoder (own workspace) with input, output, metadata and logits buffers of its own, and
+        leaves the last position's post-norm hidden state of sequence i in hidden_out[i] and its first code in
+        token_out[i] (int64; arg-max - a sampling request draws its first code from `self.pre_logits[i]` by the
+        caller).  One such prefill may be in flight at a time (the metadata staging buffer is reused: the upload of
+        the previous one is waited for here).  Same launches, same arithmetic as the synchronous path."""
+        if isinstance(seqs, Sequence):
+            seqs, hidden_out = [seqs], hidden_out.reshape(1, -1)
         if not hasattr(self, "_twin"):
             self._twin = self.decoder.twin(self.max_rows, self.config.max_model_len)
-            self.pre_logits = torch.zeros(1, self.vocab, dtype=torch.bfloat16, device=self.device)
-        N, S, cu, max_len = self.prepare_prefill([seq])
-        st, mb = self.pstage, self.max_blocks_per_seq
-        self._twin.forward(self.x_buf[:N], st.d("positions")[:N], st.d("slots")[:N], st.d("ctx")[:N],
-                           st.d("tables")[:mb].view(1, mb), max_len, row_seq=st.d("row_seq")[:N], out=self.h_buf[:N])
-        last = self.h_buf[N - 1:N]
-        hidden_out.copy_(last[0], non_blocking=True)
-        hip.linear(last, self.codec_head, self.vocab, out=self.pre_logits)
-        hip.check(hip.lib.qtts_argmax(hip.ptr(self.pre_logits), self.vocab, hip.ptr(token_out), 1, self.vocab,
+            H = self.shape.hidden_size
+            self.pre_logits = torch.zeros(self.max_bs, self.vocab, dtype=torch.bfloat16, device=self.device)
+            self.pre_x = torch.zeros(self.max_rows, H, dtype=torch.bfloat16, device=self.device)
+            self.pre_h = torch.zeros(self.max_rows, H, dtype=torch.bfloat16, device=self.device)
+            mb = self.max_blocks_per_seq
+            self.pre_stage = Staging([("positions", self.max_rows, torch.int64), ("slots", self.max_rows, torch.int32),
+                                      ("ctx", self.max_rows, torch.int32), ("row_seq", self.max_rows, torch.int32),
+                                      ("tables", self.max_bs * mb, torch.int32)], self.device)
+            self._pre_uploaded = torch.cuda.Event()
+            self._pre_uploaded.record()
+        self._pre_uploaded.synchronize()                    # the host buffer is about to be rewritten
+        N, S, cu, max_len = self.prepare_prefill(seqs, self.pre_stage, self.pre_x)
+        self._pre_uploaded.record()
+        st, mb = self.pre_stage, self.max_blocks_per_seq
+        self._twin.forward(self.pre_x[:N], st.d("positions")[:N], st.d("slots")[:N], st.d("ctx")[:N],
+                           st.d("tables")[:S * mb].view(S, mb), max_len, row_seq=st.d("row_seq")[:N], out=self.pre_h[:N])
+        # (row copies, not an index tensor: its upload would make the host wait for this stream)
+        for i in range(S):
+            hidden_out[i].copy_(self.pre_h[cu[i + 1] - 1], non_blocking=True)
+        hip.linear(hidden_out[:S], self.codec_head, self.vocab, out=self.pre_logits[:S])
+        hip.check(hip.lib.qtts_argmax(hip.ptr(self.pre_logits), self.vocab, hip.ptr(token_out), S, self.vocab,
                                       hip.stream()), "argmax")
 
     def exit(self):

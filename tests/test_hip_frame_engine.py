@@ -257,11 +257,13 @@ def test_step_finishes_a_stream_at_its_frame_budget(tmp_path):
     fe.exit()
 
 
-def test_prompts_prefilled_beside_the_running_frames_give_the_same_ids(tmp_path):
+@pytest.mark.parametrize("join", [True, False])
+def test_prompts_prefilled_beside_the_running_frames_give_the_same_ids(tmp_path, join):
     """add_stream(wait=False): the prompt is prefilled on a second HIP stream while the running streams' frames go on,
-    and joins at a frame boundary.  Three newcomers admitted at once (their prefills queue up), one of them cancelled
-    while it waits: every stream's ids equal a run of that stream alone, the running stream is not disturbed, and all
-    KV blocks come back."""
+    and joins at a frame boundary - the next one, which then waits for the rest of the prefill (join_prefills, the
+    default), or the first one after the prefill has finished.  Three newcomers admitted at once (their prefills queue
+    up), one of them cancelled while it waits: every stream's ids equal a run of that stream alone, the running stream
+    is not disturbed, and all KV blocks come back."""
     from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
     cfg, sd, tw, pw, g = fixture_model("sharp")
     json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
@@ -281,6 +283,7 @@ def test_prompts_prefilled_beside_the_running_frames_give_the_same_ids(tmp_path)
 
     want = [solo(0, 12), solo(1, 6), solo(2, 6), solo(3, 6)]
     fe = FrameEngine(str(tmp_path), **kw)
+    fe.join_prefills = join
     free0 = len(fe.talker.scheduler.block_manager.free_block_ids)
     sp = dict(talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
     a = fe.add_stream(prompts[0], texts[0], max_frames=12, **sp)
@@ -307,6 +310,62 @@ def test_prompts_prefilled_beside_the_running_frames_give_the_same_ids(tmp_path)
     while fe.streams:
         frames += [fr for fr in fe.step().values()]
     assert frames == want[3]
+    fe.exit()
+
+
+def test_requests_admitted_while_a_frame_is_in_flight_give_the_same_ids(tmp_path):
+    """step(poll=...): the serving loop's hook is called while the host waits for a frame's codes; requests admitted
+    from it (two at once: one packed prefill on the second stream; later a third into the row a finished stream has
+    left, i.e. with KV blocks that were in use a frame before; one of them sampling its first code) start beside the
+    frame in flight and join with the next frame.  Ids of the greedy streams equal a run of each alone, the stream
+    that was running is not disturbed, every KV block comes back."""
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    from nano_qwen3tts_vllm.sampling_params import SamplingParams
+    cfg, sd, tw, pw, g = fixture_model("sharp")
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    gen = torch.Generator().manual_seed(77)
+    H = cfg["talker_config"]["hidden_size"]
+    prompts = [torch.randn(L, H, generator=gen) * 0.5 for L in (11, 270, 35, 20, 8)]
+    texts = [torch.randn(12, H, generator=gen) * 0.3 for _ in prompts]
+    kw = dict(max_streams=4, max_text_frames=16, talker_weights=tw, predictor_weights=pw, num_kvcache_blocks=8,
+              max_num_batched_tokens=1024, codec_eos=None)
+    sp = dict(talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+
+    def solo(i, n):
+        fe = FrameEngine(str(tmp_path), **kw)
+        fe.add_stream(prompts[i], texts[i], max_frames=n, **sp)
+        out = fe.run_frames(n)[:, 0].tolist()
+        fe.exit()
+        return out
+
+    want = [solo(0, 10), solo(1, 3), solo(2, 5), solo(3, 4)]
+    fe = FrameEngine(str(tmp_path), **kw)
+    free0 = len(fe.talker.scheduler.block_manager.free_block_ids)
+    a = fe.add_stream(prompts[0], texts[0], max_frames=10, **sp)
+    got, ids, frame_no, polls = {a: []}, {}, [0], [0]
+
+    def poll():
+        polls[0] += 1
+        if frame_no[0] == 1 and 1 not in ids:             # two requests found waiting during frame 1
+            r = fe.add_streams([dict(prompt_embeds=prompts[i], text_adds=texts[i], max_frames=n, sid=f"s{i}", **sp)
+                                for i, n in ((1, 3), (2, 5))], wait=False)
+            assert r == ["s1", "s2"]
+            ids[1], ids[2] = r
+        if frame_no[0] == 5 and 3 not in ids:             # stream 1 has finished (3 frames): its row and blocks are free
+            assert ids[1] not in fe.streams
+            ids[3] = fe.add_stream(prompts[3], texts[3], max_frames=4, wait=False, sid="s3", **sp)
+            ids[4] = fe.add_stream(prompts[4], texts[4], max_frames=2, wait=False, sid="s4", predictor_sampling=greedy(17, 0.9),
+                                   talker_sampling=SamplingParams(temperature=1.0, max_tokens=1, do_sample=True, top_k=50))
+    while fe.streams:
+        for sid, frame in fe.step(poll=poll).items():
+            got.setdefault(sid, []).append(frame)
+        frame_no[0] += 1
+    assert polls[0] > 0 and len(ids) == 4
+    assert got[a] == want[0]
+    assert got["s1"] == want[1] and got["s2"] == want[2] and got["s3"] == want[3]
+    # newcomers found during frame 1 have their first frame two calls later at the latest (frame 2 waits for them)
+    assert len(got["s4"]) == 2 and all(0 <= c < 512 for fr in got["s4"] for c in fr)
+    assert len(fe.talker.scheduler.block_manager.free_block_ids) == free0
     fe.exit()
 
 
