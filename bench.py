@@ -269,6 +269,8 @@ def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed, ad
     state = {"nxt": 0}
     detached = admission != "serial"
     fe.join_prefills = admission == "join"
+    if os.environ.get("QTTS_LAUNCH_MARGIN_US"):      # tuning: how long before the talker step's end a frame is committed
+        fe.LAUNCH_MARGIN_S = float(os.environ["QTTS_LAUNCH_MARGIN_US"]) * 1e-6
     t0 = time.perf_counter()
     now = lambda: time.perf_counter() - t0
 

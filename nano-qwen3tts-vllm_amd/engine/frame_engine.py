@@ -52,6 +52,9 @@ class FrameEngine:
     # newcomer has its first frame as early as it can).  False: with the first frame that starts after the prefill has
     # finished (the running streams never wait; the newcomer may lose most of a frame).
     join_prefills = True
+    # step(poll=): a frame is handed to the GPU this long before the talker step in front of it is expected to end
+    # (covers the host's wake-up granularity and the time it takes to enqueue the frame's graphs)
+    LAUNCH_MARGIN_S = 3.5e-4
 
     def __init__(self, model_dir: str, max_streams: int = 8, max_text_frames: int = 1024, talker_weights=None,
                  predictor_weights=None, enforce_eager: bool = False, codec_eos: int | None = CODEC_EOS, top_k: int = 50,
@@ -114,6 +117,11 @@ class FrameEngine:
         self.code_graphs: dict[int, hip.Graph] = {}          # predictor burst + glue, per batch bucket
         self._codes_host = torch.zeros(max_streams, 16, dtype=torch.int64).pin_memory()
         self._codes_event = torch.cuda.Event()
+        # step(poll=): when the talker step in flight began (host clock) with its timing events, the events of the
+        # one before it, and the running estimate of a talker step's duration
+        self._talker_mark = None
+        self._talker_pair = None
+        self._talker_s = 0.0
         self._pred_meta_bs = None
         self._next_sid = 0
         self.stream = self.tr.stream
@@ -507,13 +515,26 @@ class FrameEngine:
         """One frame for every active stream; streams whose talker id is the codec EOS finish
         without yielding that frame (as P/interface.py:1233-1239); a stream that has produced its max_frames
         finishes with that frame (the explicit length guard the reference lacks).
-        poll: called (with no arguments; at least once, then every 50 us or so) while the host waits for the frame's codes; a serving loop
-        admits what has arrived meanwhile from it with add_stream(s)(wait=False), so a prompt's prefill starts beside
-        the frame in flight instead of after the next time the loop gets round to looking."""
+        poll: called (with no arguments; at least once, then every 50 us or so) while the host has nothing to do but
+        wait; a serving loop admits what has arrived meanwhile from it with add_stream(s)(wait=False), so a prompt's
+        prefill starts beside the frame in flight instead of after the next time the loop gets round to looking.
+        With poll the frame is also handed to the GPU as late as it can be without leaving it idle (see below)."""
+        if poll is not None and self._talker_mark is not None:
+            # The talker step that closed the previous frame is still running (about a millisecond) and this frame's
+            # codes cannot start before it ends: the frame is not committed to the GPU's queue until shortly before
+            # then.  A request that shows up in this window is prefilled right behind that talker step and is part of
+            # this frame; had the frame been launched at once, the prefill would have queued behind the whole of it.
+            begun, pair = self._talker_mark
+            deadline = begun + self._talker_s - self.LAUNCH_MARGIN_S
+            while time.perf_counter() < deadline and not pair[1].query():
+                poll()
+                time.sleep(5e-5)
+        self._talker_mark = None
         if not self.streams or not self._activate_or_wait():
             return {}
         bs = self._bucket()
         live = [s for s in self.streams.values() if s.active]      # (poll may admit and even switch on others meanwhile)
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if poll is not None else None
         with self._on_engine_stream():
             self._setup_predictor_meta(bs)
             # the frame's codes are final once the predictor burst is done: they travel to the host while the talker
@@ -522,7 +543,11 @@ class FrameEngine:
             self._launch_codes(bs)
             self._codes_host[:bs].copy_(self.codes[:bs], non_blocking=True)
             self._codes_event.record(torch.cuda.current_stream())
+            if pair:
+                pair[0].record(torch.cuda.current_stream())
             self._launch_talker(bs, self._max_ctx_bucket())
+            if pair:
+                pair[1].record(torch.cuda.current_stream())
         if poll is None:
             self._codes_event.synchronize()
         else:
@@ -531,6 +556,12 @@ class FrameEngine:
                 if self._codes_event.query():
                     break
                 time.sleep(5e-5)
+            # the codes are here, so this frame's talker step has just begun; how long it runs is taken from the
+            # previous frame's (finished by now: this frame's codes came after it)
+            if self._talker_pair is not None:
+                self._talker_s = 0.5 * self._talker_s + 0.5 * self._talker_pair[0].elapsed_time(self._talker_pair[1]) * 1e-3
+            self._talker_pair = pair
+            self._talker_mark = (time.perf_counter(), pair)
         codes = self._codes_host[:bs].tolist()
         res = {}
         for s in live:

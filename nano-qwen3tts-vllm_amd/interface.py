@@ -17,9 +17,11 @@ from __future__ import annotations
 
 import asyncio
 import functools
+import inspect
 import json
 import logging
 import os
+import threading
 import uuid
 from concurrent.futures import ThreadPoolExecutor
 
@@ -110,12 +112,18 @@ class Qwen3TTSInterface:
         self._fused_task: asyncio.Task | None = None
         self._fused_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="qtts-frame-engine")
         self._fused_pending: list = []
+        self._fused_lock = threading.Lock()      # the pending list is filled by the event loop and emptied by the engine's thread
         self._fused_cancelled: list = []
         self._fused_wake: asyncio.Event | None = None
         self.max_streams = int(os.environ.get("QTTS_MAX_STREAMS", "8"))
-        # QTTS_OVERLAP_PREFILL=1: a new prompt is prefilled on a second stream beside the running frames
-        # (add_stream(wait=False)): steadier frames for the running streams, a later first frame for the newcomer
-        self._admit_wait = os.environ.get("QTTS_OVERLAP_PREFILL", "0") != "1"
+        # How the fused loop admits a request.  "join" (default): its prompt is prefilled on the engine's second HIP
+        # stream from the moment it is seen - also while a frame is in flight - and it joins with the next frame, which
+        # waits for the rest of the prefill.  "serial": prefill between two frames on the engine's one stream.
+        # "beside" (QTTS_OVERLAP_PREFILL=1 means this): as "join", but the running streams never wait - the newcomer
+        # joins with the first frame after its prefill has finished.
+        self._admission = os.environ.get("QTTS_ADMISSION") or ("beside" if os.environ.get("QTTS_OVERLAP_PREFILL", "0") == "1" else "join")
+        if self._admission not in ("join", "serial", "beside"):
+            raise ValueError(f"QTTS_ADMISSION={self._admission!r}: expected join, serial or beside")
         self.do_sample = True            # the reference always samples (T=1.0 talker, T=0.9 predictor, top-k 50)
         self.max_frames = 1024           # explicit stop: the reference has no length guard (ends only on codec EOS)
         self.ignore_eos = False          # benchmarks with random weights: keep generating through codec id 2150
@@ -214,67 +222,103 @@ class Qwen3TTSInterface:
 
     # ---------------------------------------------------------------- async path (one loop over the frame engine)
     async def _run_fused_loop(self) -> None:
-        """Continuous batching over the frame engine: between two frames, streams whose consumer went away are
-        dropped and waiting requests are admitted (their prefill runs there); every frame goes to its
-        request's queue, `None` ends a stream (codec EOS, frame budget, or no free row / KV block)."""
+        """Continuous batching over the frame engine: streams whose consumer went away are dropped between two frames,
+        waiting requests are admitted between two frames and - with an engine whose step takes a `poll` hook - also
+        while a frame is in flight (their packed prefill then starts at once on the engine's second stream and they
+        join with the next frame); every frame goes to its request's queue, `None` ends a stream (codec EOS, frame
+        budget, or no free row / KV block)."""
         from .engine.frame_engine import NoCapacity
         fe = self._frame_engine
         budget: dict[str, int] = {}
         # The engine's blocking calls (a frame: about 3 ms until the codes are on the host; an admission: the prompt's
         # prefill) run on one worker thread, so the event loop keeps serving its other coroutines - an HTTP server's
-        # handlers, the streams' consumers - meanwhile.  Only this coroutine talks to the engine, one call at a time.
+        # handlers, the streams' consumers - meanwhile.  One call at a time talks to the engine.
         loop = asyncio.get_running_loop()
 
         def off_loop(fn, *a, **k):
             return loop.run_in_executor(self._fused_pool, functools.partial(fn, *a, **k))
+
+        def takes(fn, name):
+            try:
+                return name in inspect.signature(fn).parameters
+            except (TypeError, ValueError):
+                return False
+        packed = hasattr(fe, "add_streams")
+        # admission while a frame is in flight needs the hook and a prefill that does not wait for the host
+        in_flight = self._admission != "serial" and packed and takes(fe.step, "poll") and takes(fe.add_streams, "wait")
+        if hasattr(fe, "join_prefills"):
+            fe.join_prefills = self._admission != "beside"
+        detached = self._admission != "serial" and getattr(fe, "overlapped_admission", False)
+        admitted: list = []              # (requests, results) of engine admissions, settled by this coroutine
+
+        def admit():
+            """What can be admitted now goes to the engine in ONE call: prompts that arrived together are prefilled
+            packed (the reference's scheduler does the same with what its collection window gathers).  Runs on the
+            worker thread, between two frames or from the engine's hook while one is in flight; the batch leaves the
+            pending list first, requests that arrive meanwhile are appended behind."""
+            if not self._fused_pending:
+                return
+            if admitted and any(isinstance(r, Exception) for r in admitted[-1][1]):
+                return                    # a request the engine has just refused for lack of room is not retried at once
+            room = max(fe.max_streams - len(fe.streams), 0)
+            with self._fused_lock:
+                batch = self._fused_pending[:room]
+                del self._fused_pending[:room]
+            if not batch:
+                return
+            if packed:
+                kw = {"wait": False} if (detached and takes(fe.add_streams, "wait")) else {}
+                results = fe.add_streams([dict(prompt_embeds=p_, text_adds=t_, max_frames=n, talker_sampling=tsp,
+                                               predictor_sampling=psp, sid=rid) for rid, p_, t_, n, tsp, psp in batch], **kw)
+            else:
+                results = []
+                for rid, p_, t_, n, tsp, psp in batch:
+                    try:
+                        results.append(fe.add_stream(p_, t_, max_frames=n, talker_sampling=tsp, predictor_sampling=psp, sid=rid,
+                                                     wait=not detached))
+                    except (NoCapacity, AssertionError, ValueError) as e:
+                        results.append(e)
+            # (whether the engine was serving anything is judged now: by the time this is settled a stream may have ended)
+            admitted.append((batch, results, bool(fe.streams)))
+
+        def settle():
+            retry = []
+            for batch, results, busy in admitted:
+                for req, r in zip(batch, results):
+                    rid = req[0]
+                    if not isinstance(r, Exception):
+                        if rid in self._request_queues:
+                            budget[rid] = req[3]
+                        else:                                             # its consumer went away during the prefill
+                            fe.remove_stream(rid)
+                        continue
+                    if isinstance(r, NoCapacity) and busy:               # blocks come back when a running stream ends
+                        retry.append(req)
+                        continue
+                    logger.warning(f"[fused_loop] request {rid[:8]} rejected: {r}")     # can never be served
+                    q = self._request_queues.get(rid)
+                    if q is not None:
+                        q.put_nowait(None)
+            admitted.clear()
+            with self._fused_lock:
+                self._fused_pending[:0] = [r for r in retry if r[0] in self._request_queues]
+
         while True:
             for rid in self._fused_cancelled:
                 fe.remove_stream(rid)
                 budget.pop(rid, None)
             self._fused_cancelled.clear()
-            # what can be admitted now goes to the engine in ONE call: prompts that arrived together are prefilled
-            # packed (the reference's scheduler does the same with what its collection window gathers).  The batch
-            # leaves the pending list before the engine is awaited: requests that arrive meanwhile are appended behind.
-            room = max(fe.max_streams - len(fe.streams), 0)
-            batch = self._fused_pending[:room]
-            del self._fused_pending[:room]
-            if batch and self._admit_wait and hasattr(fe, "add_streams"):
-                results = await off_loop(fe.add_streams, [dict(prompt_embeds=p_, text_adds=t_, max_frames=n, talker_sampling=tsp,
-                                                                 predictor_sampling=psp, sid=rid)
-                                                            for rid, p_, t_, n, tsp, psp in batch])
-            else:
-                results = []
-                for rid, p_, t_, n, tsp, psp in batch:
-                    try:
-                        results.append(await off_loop(fe.add_stream, p_, t_, max_frames=n, talker_sampling=tsp,
-                                                      predictor_sampling=psp, sid=rid, wait=self._admit_wait))
-                    except (NoCapacity, AssertionError, ValueError) as e:
-                        results.append(e)
-            retry = []
-            for req, r in zip(batch, results):
-                rid = req[0]
-                if not isinstance(r, Exception):
-                    if rid in self._request_queues:
-                        budget[rid] = req[3]
-                    else:                                             # its consumer went away during the prefill
-                        fe.remove_stream(rid)
-                    continue
-                if isinstance(r, NoCapacity) and fe.streams:         # blocks come back when a running stream ends
-                    retry.append(req)
-                    continue
-                logger.warning(f"[fused_loop] request {rid[:8]} rejected: {r}")     # can never be served
-                q = self._request_queues.get(rid)
-                if q is not None:
-                    q.put_nowait(None)
-            self._fused_pending[:0] = [r for r in retry if r[0] in self._request_queues]
+            await off_loop(admit)
+            settle()
             if not fe.streams:
                 self._fused_wake.clear()
                 if not self._fused_pending:
                     await self._fused_wake.wait()
                 continue
             active = list(fe.streams)
-            res = await off_loop(fe.step)
-            for rid in active:
+            res = await (off_loop(fe.step, poll=admit) if in_flight else off_loop(fe.step))
+            settle()                      # requests admitted while the frame was in flight: budgets before frames
+            for rid in active + [r for r in res if r not in active]:
                 q = self._request_queues.get(rid)
                 frame = res.get(rid)
                 if frame is not None and q is not None:
@@ -298,7 +342,8 @@ class Qwen3TTSInterface:
         q: asyncio.Queue = asyncio.Queue()
         async with self._queues_lock:
             self._request_queues[request_id] = q
-        self._fused_pending.append((request_id, prompt, text_adds, n, tsp, psp))
+        with self._fused_lock:
+            self._fused_pending.append((request_id, prompt, text_adds, n, tsp, psp))
         self._fused_wake.set()
         try:
             while True:
@@ -309,7 +354,8 @@ class Qwen3TTSInterface:
         finally:
             async with self._queues_lock:
                 self._request_queues.pop(request_id, None)
-            self._fused_pending[:] = [r for r in self._fused_pending if r[0] != request_id]
+            with self._fused_lock:
+                self._fused_pending[:] = [r for r in self._fused_pending if r[0] != request_id]
             if request_id in fe.streams:
                 self._fused_cancelled.append(request_id)
                 self._fused_wake.set()

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import asyncio
 import importlib
+import inspect
 import multiprocessing as mp
 import os
 import queue
@@ -68,44 +69,62 @@ def replica_main(index: int, device_index: int | None, factory: str, factory_kwa
         return
     res_q.put(("__replica__", index, "ready", None))
     from .sampling_params import SamplingParams
-    # QTTS_OVERLAP_PREFILL=1: an engine that can prefill a new prompt beside the running frames is asked to
-    overlap = os.environ.get("QTTS_OVERLAP_PREFILL", "0") == "1" and getattr(engine, "overlapped_admission", False)
-    admit_kw = {"wait": False} if overlap else {}
+
+    def takes(fn, name):
+        try:
+            return name in inspect.signature(fn).parameters
+        except (TypeError, ValueError):
+            return False
+    # QTTS_ADMISSION: "join" (default; with an engine that can prefill on a second stream: requests are admitted from
+    # the moment they arrive, also while a frame is in flight, and join with the next frame), "serial" (prefill
+    # between two frames), "beside" (as join, but the running streams never wait for a prefill; QTTS_OVERLAP_PREFILL=1)
+    admission = os.environ.get("QTTS_ADMISSION") or ("beside" if os.environ.get("QTTS_OVERLAP_PREFILL", "0") == "1" else "join")
+    detached = admission != "serial" and getattr(engine, "overlapped_admission", False)
+    packed = hasattr(engine, "add_streams")
+    in_flight = detached and packed and takes(engine.step, "poll") and takes(engine.add_streams, "wait")
+    if hasattr(engine, "join_prefills"):
+        engine.join_prefills = admission != "beside"
     waiting: list = []
-    running = True
-    while running or engine.streams:
-        # commands: block only when there is nothing to run
-        block = not engine.streams and not waiting
+    state = {"running": True}
+
+    def take_commands(block: bool):
         while True:
             try:
                 cmd = cmd_q.get(block=block, timeout=0.5 if block else None)
             except queue.Empty:
-                break
+                return
             block = False
             if cmd[0] == _CMD_SHUTDOWN:
-                running = False
+                state["running"] = False
                 waiting.clear()
                 for sid in list(engine.streams):
                     engine.remove_stream(sid)
             elif cmd[0] == _CMD_CANCEL:
                 waiting[:] = [w for w in waiting if w[1] != cmd[1]]
                 engine.remove_stream(cmd[1])
-            elif cmd[0] == _CMD_ADD and running:
+            elif cmd[0] == _CMD_ADD and state["running"]:
                 waiting.append(cmd)
-        still = []
+
+    def admit():
+        """What fits goes to the engine in one call (prompts that arrived together: one packed prefill)."""
+        if not waiting:
+            return
         room = max(getattr(engine, "max_streams", len(waiting)) - len(engine.streams), 0)
         batch, later = waiting[:room], waiting[room:]
+        if not batch:
+            return
         reqs = [dict(prompt_embeds=_to_tensor(c[2]), text_adds=_to_tensor(c[3]), max_frames=c[4],
                      talker_sampling=SamplingParams(**c[5]), predictor_sampling=SamplingParams(**c[6]), sid=c[1]) for c in batch]
-        if reqs and not admit_kw and hasattr(engine, "add_streams"):
-            results = engine.add_streams(reqs)             # prompts that arrived together: one packed prefill
+        if packed and (not detached or takes(engine.add_streams, "wait")):
+            results = engine.add_streams(reqs, **({"wait": False} if detached else {}))
         else:
             results = []
             for r in reqs:
                 try:
-                    results.append(engine.add_stream(**r, **admit_kw))
+                    results.append(engine.add_stream(**r, **({"wait": False} if detached else {})))
                 except Exception as e:
                     results.append(e)
+        still = []
         for cmd, r in zip(batch, results):
             if not isinstance(r, Exception):
                 continue
@@ -113,23 +132,30 @@ def replica_main(index: int, device_index: int | None, factory: str, factory_kwa
                 still.append(cmd)                          # a row / KV blocks come back when a running stream ends
             else:
                 res_q.put((cmd[1], _END, f"rejected: {r}"))
-        still += later
-        waiting[:] = still
+        waiting[:] = still + later
+
+    def poll():
+        take_commands(False)
+        admit()
+
+    while state["running"] or engine.streams:
+        take_commands(block=not engine.streams and not waiting)      # block only when there is nothing to run
+        admit()
         if not engine.streams:
             continue
         active = list(engine.streams)
         try:
-            frames = engine.step()
+            frames = engine.step(poll=poll) if in_flight else engine.step()
         except Exception:
             err = traceback.format_exc()
             for rid in active:
                 res_q.put((rid, _END, "engine error: " + err))
                 engine.remove_stream(rid)
             continue
-        for rid in active:
+        for rid in active + [r for r in frames if r not in active]:
             if rid in frames:
                 res_q.put((rid, list(frames[rid]), None))
-            if rid not in engine.streams:              # codec EOS or the stream's frame budget
+            if rid not in engine.streams:              # codec EOS or the stream's frame budget (or cancelled meanwhile)
                 res_q.put((rid, _END, "finished"))
     if hasattr(engine, "exit"):
         engine.exit()

@@ -59,3 +59,34 @@ class FakeFrameEngine:
 
     def exit(self):
         self.streams.clear()
+
+
+class FakePollingFrameEngine(FakeFrameEngine):
+    """The same with the serving hooks of the real engine: add_streams(wait=False) and step(poll=...), which calls the
+    hook while its 'frame is in flight' (a short sleep), so that requests queued meanwhile are admitted from inside
+    step.  Streams admitted from the hook before the frame is 'committed' (the first hook call) take part in it."""
+    overlapped_admission = True
+    join_prefills = True
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.admitted_in_flight = 0
+        self._in_step = False
+
+    def add_streams(self, requests, wait=True):
+        if self._in_step:
+            self.admitted_in_flight += sum(1 for _ in requests)
+        return super().add_streams(requests)
+
+    def step(self, poll=None):
+        import time
+        if poll is not None:
+            self._in_step = True
+            poll()                                   # (before the frame is committed: newcomers are part of it)
+        out = super().step()
+        if poll is not None:
+            for _ in range(3):                       # the frame is in flight
+                time.sleep(0.002)
+                poll()
+            self._in_step = False
+        return out

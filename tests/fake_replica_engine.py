@@ -57,3 +57,43 @@ def make(**kw):
 
 def broken(**kw):
     raise RuntimeError("no engine today")
+
+
+class FakePollingEngine(FakeEngine):
+    """With the real engine's serving hooks: add_streams(wait=False) and step(poll=...), which calls the hook while its
+    frame is 'in flight'.  Frames carry, in slot 4, whether the stream was admitted from inside a step."""
+    overlapped_admission = True
+    join_prefills = True
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self._in_step = False
+
+    def add_streams(self, requests, wait=True):
+        out = []
+        for r in requests:
+            try:
+                sid = self.add_stream(**r)
+                self.streams[sid].in_flight = self._in_step
+                out.append(sid)
+            except Exception as e:
+                out.append(e)
+        return out
+
+    def step(self, poll=None):
+        if poll is not None:
+            self._in_step = True
+            poll()
+        out = super().step()
+        for sid, fr in out.items():
+            fr[4] = int(getattr(self.streams.get(sid), "in_flight", False)) if sid in self.streams else fr[4]
+        if poll is not None:
+            for _ in range(3):
+                time.sleep(self.step_seconds / 3)
+                poll()
+            self._in_step = False
+        return out
+
+
+def make_polling(**kw):
+    return FakePollingEngine(**kw)

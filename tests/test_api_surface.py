@@ -235,3 +235,51 @@ def test_orchestrator_loops_put_the_reference_messages_on_the_request_queues():
     assert got == want
     assert want["talker"]["queues"]["b"][-1] == ["talker", "done", {}]
     assert want["talker"]["idle_calls"] == 0 and want["talker"]["client_calls"] == 5
+
+
+def test_fused_loop_admits_requests_while_a_frame_is_in_flight(model_dir, monkeypatch):
+    """The fused loop hands the engine a hook (step(poll=...)): requests that arrive while the engine's thread is busy
+    with a frame are admitted from inside that call (add_streams(wait=False)) instead of after it.  With a stand-in
+    engine on the CPU: every request gets all its frames in order, nothing is lost or duplicated when a stream is
+    admitted mid-frame, a consumer that leaves early releases its row, and some admissions did come through the hook."""
+    import fake_frame_engine
+    from nano_qwen3tts_vllm.engine import frame_engine as FE
+    from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
+    monkeypatch.setenv("QTTS_ASYNC_ENGINE", "fused")
+    monkeypatch.delenv("QTTS_ADMISSION", raising=False)
+    monkeypatch.setattr(FE, "FrameEngine", fake_frame_engine.FakePollingFrameEngine)
+    iface = Qwen3TTSInterface.from_pretrained(model_dir)
+    iface.max_streams = 3
+    H = iface.model_config.talker_config.hidden_size
+    gen = torch.Generator().manual_seed(5)
+    prompts = [torch.randn(1, 4 + i, H, generator=gen) for i in range(7)]
+    trailing = torch.randn(1, 3, H, generator=gen)
+    pad = torch.randn(1, 1, H, generator=gen)
+
+    def want(pr):
+        key = int(pr.reshape(-1, H).float().abs().sum().item() * 7) % 1000
+        return [[(key + n * 17 + c) % 256 for c in range(16)] for n in range(fake_frame_engine.FRAMES)]
+
+    async def run():
+        await iface.start_zmq_tasks()
+        fe = iface._frame_engine
+
+        async def one(i):
+            await asyncio.sleep(0.003 * i)              # arrivals spread over the frames of the earlier requests
+            return [f async for f in iface.generate_async(prompts[i], trailing, pad, None, request_id=f"r{i}")]
+        res = await asyncio.gather(*[one(i) for i in range(6)])
+        agen = iface.generate_async(prompts[6], trailing, pad, None, request_id="early")
+        first = await agen.__anext__()
+        await agen.aclose()
+        await asyncio.sleep(0.05)
+        left = dict(fe.streams)
+        n = fe.admitted_in_flight
+        await iface.stop_zmq_tasks()
+        return res, first, left, n
+
+    res, first, left, n = asyncio.run(run())
+    for i, got in enumerate(res):
+        assert got == want(prompts[i]), i
+    assert first == want(prompts[6])[0] and not left
+    assert n > 0, "no request was admitted from the engine's hook"
+    assert not iface._request_queues

@@ -146,3 +146,29 @@ def test_two_replica_processes_with_the_real_engine(tmp_path):
     finally:
         pool.close()
     assert got == want
+
+
+def test_replica_admits_requests_while_a_frame_is_in_flight():
+    """A replica whose engine offers the serving hooks (step(poll=...), add_streams(wait=False)) takes commands and
+    admits what fits from inside the engine's step: requests submitted while the first streams run are admitted
+    mid-frame (slot 4 of their frames says so), every stream still gets exactly its frames in order, a cancellation
+    that arrives mid-frame takes effect, and the loads return to zero."""
+    p = ReplicaPool(1, "fake_replica_engine:make_polling", dict(max_streams=4, step_seconds=0.006),
+                    max_streams_per_replica=4, start_timeout=120)
+    try:
+        text = torch.zeros(2, 8)
+        first = p.submit(_prompt(5), text, max_frames=60, request_id="first")
+        it = p.frames(first)
+        assert next(it)[1] == 0                              # the replica is stepping now
+        rids = [p.submit(_prompt(20 + i), text, max_frames=10 + i, request_id=f"mid{i}") for i in range(2)]
+        doomed = p.submit(_prompt(99), text, max_frames=500, request_id="doomed")
+        got = {rid: list(p.frames(rid)) for rid in rids}
+        for i, rid in enumerate(rids):
+            assert [f[1] for f in got[rid]] == list(range(10 + i)) and all(f[0] == 20 + i for f in got[rid])
+        assert any(f[4] == 1 for rid in rids for f in got[rid]), "nothing was admitted from inside a step"
+        p.cancel(doomed)
+        rest = list(it)
+        assert [f[1] for f in rest] == list(range(1, 60))
+        assert p.load() == [0]
+    finally:
+        p.close()
