@@ -219,7 +219,7 @@ extern "C" int qtts_pack_gate_up_fp8(const void *gate, const void *up, void *pac
 static int g_tune_ksw = 0;   // 0 = automatic
 static int g_tune_t = 0;
 static int g_dbg_linear = 0;
-static int g_rows_min = 32;              // most rows that still take single-tile workgroups instead of the prompt GEMM
+static int g_rows_min = 16;              // most rows that still take single-tile workgroups instead of the prompt GEMM
 static int g_share_prologue = 1;         // norm prologue shared between the lane halves for up to 8 rows (0: tuning)
 static int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
 static int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention takes the MFMA kernel for prompts
@@ -236,7 +236,7 @@ static int g_trace_launch = 0;
 extern "C" void qtts_debug_linear_trace(long long *buf) { g_trace = buf; g_trace_launch = 0; }
 #else
 static constexpr int g_tune_ksw = 0, g_tune_t = 0, g_dbg_linear = 0;
-static constexpr int g_rows_min = 32;              // most rows that still take single-tile workgroups instead of the prompt GEMM
+static constexpr int g_rows_min = 16;              // most rows that still take single-tile workgroups instead of the prompt GEMM
 static constexpr int g_share_prologue = 1;         // norm prologue shared between the lane halves for up to 8 rows
 static constexpr int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
 static constexpr int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention takes the MFMA kernel for prompts
@@ -1159,7 +1159,8 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     QCHECK(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.wp & 15) == 0 && ((uintptr_t)a.out & 7) == 0, "linear: misaligned pointer");
     QCHECK(pro != 1 || a.nw, "linear: norm prologue without weight");
     QCHECK(!a.xnorm_out || (a.ldxn % 8 == 0 && a.ldxn >= a.K), "linear: bad xnorm_out stride");
-    // from three row tiles on; with two, single-tile workgroups are faster (a frame at 32 streams: 4.79 against 5.01 ms)
+    // from two row tiles on (two row tiles per workgroup in the prompt kernel against single-tile workgroups: frames at
+    // 20 / 24 / 32 streams 4.41 / 4.42 / 4.52 -> 4.13 / 4.20 / 4.31 ms, a 17..32-token prompt 2.07 -> 1.75 ms)
     QCHECK(!a.res_ids || (a.M <= 16 && a.res && a.res_id_rows > 0 && !a.ids && !a.bias), "linear: gathered residual rows need M <= 16, a residual table and plain x rows");
     if (a.M > g_rows_min && pro == 0 && !a.ids && !(g_dbg_linear & 2) && launch_linear_rows(a, silu_pairs, scratch, scratch_bytes, s)) {
         QLAUNCH();

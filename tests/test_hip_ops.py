@@ -529,10 +529,10 @@ def test_linear_fp8_equals_bf16_on_dequantised_weights(hip, M, N, K, kind):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("M,N,K", [(33, 2048, 2048), (48, 4096, 1024), (40, 1024, 3072), (64, 2048, 6144), (100, 1024, 3072),
+@pytest.mark.parametrize("M,N,K", [(17, 4096, 2048), (24, 2048, 6144), (32, 2048, 1024), (33, 2048, 2048), (48, 4096, 1024), (40, 1024, 3072), (64, 2048, 6144), (100, 1024, 3072),
                                    (96, 4096, 2048), (200, 4096, 2048), (600, 2048, 6144)])
 def test_prompt_gemm_row_group_forms(hip, M, N, K):
-    """From 33 rows a GEMM takes the prompt kernel: row groups of two, three or four 16-row tiles (chosen per shape; two
+    """From 17 rows a GEMM takes the prompt kernel: row groups of two, three or four 16-row tiles (chosen per shape; two
     for K = 3072, twelve k-steps per wave), K = 6144 as K parts through the workspace; partial last tiles and groups."""
     g = torch.Generator().manual_seed(M * N + K)
     x = torch.randn(M, K, generator=g).bfloat16()

@@ -4,6 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _tuning  # noqa: F401  (the -DQTTS_TUNING build of the library)
 from nano_qwen3tts_vllm import hip
 hip.lib.qtts_debug_linear(int(os.environ.get("QTTS_LINEAR_DBG", "0")))
+if os.environ.get("QTTS_ROWS_MIN"):
+    hip.lib.qtts_tune_rows(int(os.environ["QTTS_ROWS_MIN"]))      # most rows that still take single-tile workgroups
+if os.environ.get("QTTS_ROWS_TM"):
+    hip.lib.qtts_tune_rows_tm(int(os.environ["QTTS_ROWS_TM"]))
 sys.argv = ["bench.py"] + sys.argv[1:]
 import bench
 bench.main()

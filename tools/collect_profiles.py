@@ -46,10 +46,11 @@ def main():
         f = glob.glob(os.path.join(R, name, "**", "*counter_collection.csv"), recursive=True)[0]
         v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if match in r["Kernel_Name"] and r["Counter_Name"] == counter]
         return statistics.median(v), len(v)
-    if os.path.exists(os.path.join(R, "bench_overlap1.json")):
+    if os.path.exists(os.path.join(R, "bench_admission_serial.json")):
         json.dump({"source": "python bench.py (arrivals workload: 8 streams 50 ms apart, 125 frames each), same box, same build",
-                   "prefill between two frames (default)": bench["arrivals"],
-                   "prefill on a second stream beside the frames (QTTS_OVERLAP_PREFILL=1)": last_json(os.path.join(R, "bench_overlap1.json"))["arrivals"]},
+                   "join (default): requests admitted while a frame is in flight, prefill on a second stream, the next frame waits for it": bench["arrivals"],
+                   "serial (QTTS_ADMISSION=serial): prefill between two frames": last_json(os.path.join(R, "bench_admission_serial.json"))["arrivals"],
+                   "beside (QTTS_ADMISSION=beside): prefill on a second stream, joined once finished": last_json(os.path.join(R, "bench_admission_beside.json"))["arrivals"]},
                   open(os.path.join(P, "r02_arrivals_admission_ab.json"), "w"), indent=1)
     fs, n = med("pmc_fetch", "FETCH_SIZE", "linear2_kernel<8, 1, true, 1")
     ws, _ = med("pmc_write", "WRITE_SIZE", "linear2_kernel<8, 1, true, 1")

@@ -433,6 +433,8 @@ def prefill():
     sp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
     hip.lib.qtts_debug_linear(int(os.environ.get("QTTS_LINEAR_DBG", "0")))
     hip.lib.qtts_tune_rows_tm(int(os.environ.get("QTTS_ROWS_TM", "0")))
+    if os.environ.get("QTTS_ROWS_MIN"):
+        hip.lib.qtts_tune_rows(int(os.environ["QTTS_ROWS_MIN"]))
     if os.environ.get("QTTS_MFMA_ATTN_ROWS"):
         hip.lib.qtts_tune_prompt_attention(int(os.environ["QTTS_MFMA_ATTN_ROWS"]))
     for plen in [int(v) for v in os.environ.get("QTTS_FRAME_PROMPT", "200").split(",")]:

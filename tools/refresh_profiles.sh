@@ -25,9 +25,11 @@ QTTS_ROWS=200 timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BU
 step prefill
 QTTS_FRAME_PROMPT=16,48,128,200,400,900 timeout -k 10 300 python3 -u $R/tools/microbench.py prefill > $O/prefill.txt 2>> $O/err.log
 QTTS_FRAME_PROMPT=200 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/prefill_trace -- python3 $R/tools/microbench.py prefill >> $O/prof.log 2>&1
-step arrivals-overlap
+step arrivals-admission
 cd $R
-QTTS_OVERLAP_PREFILL=1 timeout -k 10 300 python3 -u bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_overlap1.json 2>> $O/err.log
+for m in serial beside; do
+  QTTS_ADMISSION=$m timeout -k 10 300 python3 -u bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_admission_$m.json 2>> $O/err.log
+done
 step two-ranks
 QTTS_BENCH_REHEARSAL=1 timeout -k 10 400 python3 -u bench.py --gpus 2 --steps 50 --warmup 5 > $O/bench_2rank_rehearsal.json 2>> $O/err.log
 step configs
