@@ -1,5 +1,5 @@
-"""GPU: the soak schedule of tools/soak.py on the fixture-sized model — random single / packed / beside-the-frames
-admissions, prompts of 4 to 700 tokens, budgets of 1 to 300 frames, sampling requests, cancellations — with its
+"""GPU: the soak schedule of tools/soak.py on the fixture-sized model — random single / packed / beside-the-frames /
+mid-frame admissions, prompts of 4 to 700 tokens, budgets of 1 to 300 frames, sampling requests, cancellations — with its
 invariants (ids in range, budgets met exactly, every KV block returned) and, for a schedule that does not depend on
 GPU timing, two runs on fresh engines that must agree id for id, sampled streams included."""
 import importlib.util
@@ -29,7 +29,8 @@ def test_soak_schedule_invariants_and_run_to_run_determinism(tmp_path, monkeypat
     args = (str(tmp_path), H, tv, pv, tw, pw, dev)
     finished, counts = soak.run_schedule(3, 600, *args, timing_free=False)
     assert counts["packed"] > 5 and counts["overlapped"] > 5 and counts["cancelled"] > 5 and counts["sampled"] > 10
+    assert counts["in_flight"] > 2                           # some requests were admitted from the engine's hook, mid-frame
     a, ca = soak.run_schedule(21, 300, *args, timing_free=True)
     b, _ = soak.run_schedule(21, 300, *args, timing_free=True)
-    assert sorted(a) == sorted(b) and len(a) > 20 and ca["sampled"] > 3
+    assert sorted(a) == sorted(b) and len(a) > 20 and ca["sampled"] > 3 and ca["overlapped"] > 3     # (detached prefills replay too)
     assert [sid for sid in a if a[sid] != b[sid]] == []

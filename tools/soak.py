@@ -1,4 +1,5 @@
-"""Soak run of the frame engine at 1.7B shapes: random arrivals (single, packed, prefilled beside the frames),
+"""Soak run of the frame engine at 1.7B shapes: random arrivals (single, packed, prefilled beside the frames singly and
+packed, admitted from the engine's hook while a frame is in flight),
 prompt lengths from 4 tokens to most of the model's 1024 positions, random frame budgets, greedy and sampling
 requests, random cancellations.
 
@@ -43,7 +44,7 @@ def run_schedule(seed, steps, d, H, tv, pv, tw, pw, dev, timing_free):
     greedy = (SamplingParams(temperature=1.0, max_tokens=1, do_sample=False), SamplingParams(temperature=0.9, max_tokens=17, do_sample=False))
     sample = (SamplingParams(temperature=1.0, max_tokens=1, do_sample=True), SamplingParams(temperature=0.9, max_tokens=17, do_sample=True))
     live, finished = {}, {}
-    counts = dict(admitted=0, packed=0, overlapped=0, cancelled=0, no_capacity=0, frames=0, sampled=0)
+    counts = dict(admitted=0, packed=0, overlapped=0, in_flight=0, cancelled=0, no_capacity=0, frames=0, sampled=0)
     n_req = 0
 
     def new_request():
@@ -60,6 +61,24 @@ def run_schedule(seed, steps, d, H, tv, pv, tw, pw, dev, timing_free):
         counts["admitted"] += 1
         counts["sampled"] += int(req["talker_sampling"].do_sample)
 
+    # detached prefills join with the next frame (join_prefills): which frame that is does not depend on GPU timing, so
+    # they are part of the replayed schedule too; joining once the prefill has finished (the other policy) and
+    # admissions from the engine's hook while a frame is in flight are timing-dependent and stay in phase 1
+    fe.join_prefills = timing_free or rnd.random() < 0.5
+    hook = {"reqs": None}
+
+    def poll():
+        reqs, hook["reqs"] = hook["reqs"], None
+        if reqs:
+            for req, res in zip(reqs, fe.add_streams(reqs, wait=False)):
+                if isinstance(res, NoCapacity):
+                    counts["no_capacity"] += 1
+                elif isinstance(res, Exception):
+                    raise res
+                else:
+                    track(req)
+                    counts["in_flight"] += 1
+
     step = 0
     while step < steps or fe.streams:
         step += 1
@@ -68,7 +87,8 @@ def run_schedule(seed, steps, d, H, tv, pv, tw, pw, dev, timing_free):
             how = rnd.random()
             if how < 0.4 and room >= 2:                       # several at once: one packed prefill
                 reqs = [new_request() for _ in range(rnd.randint(2, room))]
-                for req, res in zip(reqs, fe.add_streams(reqs)):
+                detached = rnd.random() < 0.4                 # ... on the second stream, beside the frames
+                for req, res in zip(reqs, fe.add_streams(reqs, wait=not detached)):
                     if isinstance(res, NoCapacity):
                         counts["no_capacity"] += 1
                     elif isinstance(res, Exception):
@@ -76,9 +96,12 @@ def run_schedule(seed, steps, d, H, tv, pv, tw, pw, dev, timing_free):
                     else:
                         track(req)
                         counts["packed"] += 1
+                        counts["overlapped"] += int(detached)
+            elif how >= 0.9 and not timing_free and fe.streams:
+                hook["reqs"] = [new_request() for _ in range(rnd.randint(1, min(2, room)))]     # found while the frame is in flight
             else:
                 req = new_request()
-                overlap = how >= 0.8 and not timing_free       # joins when its prefill has finished: GPU timing decides the frame
+                overlap = how >= 0.7
                 try:
                     fe.add_stream(**req, wait=not overlap)
                     track(req)
@@ -90,7 +113,7 @@ def run_schedule(seed, steps, d, H, tv, pv, tw, pw, dev, timing_free):
             fe.remove_stream(sid)
             finished[sid] = live.pop(sid)["frames"]
             counts["cancelled"] += 1
-        for sid, frame in fe.step().items():
+        for sid, frame in fe.step(poll=poll if hook["reqs"] else None).items():
             assert sid in live, f"frame for unknown stream {sid}"
             assert len(frame) == 16 and 0 <= frame[0] < tv and all(0 <= c < pv for c in frame[1:]), (sid, frame)
             live[sid]["frames"].append(frame)
