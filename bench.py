@@ -400,14 +400,14 @@ def main():
     # by rank 0 at N = 1 beside the contract number)
     arrivals = None
     if not args.no_arrivals and world == 1:
-        overlap = os.environ.get("QTTS_ADMISSION", "join")
-        assert overlap in ADMISSION_MODES, overlap
-        run_arrivals(fe, device, H, 2, 3, 0.0, lens, (greedy_t, greedy_p), 1999, overlap)      # (first use of the second stream)
-        arrivals = run_arrivals(fe, device, H, B, ARRIVAL_FRAMES, ARRIVAL_GAP_S, lens, (greedy_t, greedy_p), 2000 + rank, overlap)
+        admission = os.environ.get("QTTS_ADMISSION", "join")
+        assert admission in ADMISSION_MODES, admission
+        run_arrivals(fe, device, H, 2, 3, 0.0, lens, (greedy_t, greedy_p), 1999, admission)      # (first use of the second stream)
+        arrivals = run_arrivals(fe, device, H, B, ARRIVAL_FRAMES, ARRIVAL_GAP_S, lens, (greedy_t, greedy_p), 2000 + rank, admission)
         assert not fe.streams
         # the same requests all at once (the reference's batch_async_example.py fires its streams together): admission packs
         # the prompts into one prefill
-        together = run_arrivals(fe, device, H, B, ARRIVAL_FRAMES, 0.0, lens, (greedy_t, greedy_p), 3000 + rank, overlap)
+        together = run_arrivals(fe, device, H, B, ARRIVAL_FRAMES, 0.0, lens, (greedy_t, greedy_p), 3000 + rank, admission)
         arrivals["all_at_once"] = {k: together[k] for k in ("first_chunk_ms_p50", "first_chunk_ms_p99", "inter_chunk_ms_p50",
                                                             "inter_chunk_ms_p99", "codec_tokens_per_s", "elapsed_s")}
         assert not fe.streams

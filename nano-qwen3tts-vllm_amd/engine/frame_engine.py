@@ -43,6 +43,7 @@ class Stream:
         self.finished = False
         self.active = True            # False while the stream's prefill is still running beside the frames
         self.ready = None             # the event that prefill ends with
+        self.row_written = False      # the row's per-stream state has been queued (_write_row)
 
 
 class FrameEngine:
@@ -187,12 +188,13 @@ class FrameEngine:
                 rows = 0
             groups[-1].append(s)
             rows += s.prompt_len
+        for s in streams:
+            s.active = False
+        self._prefill_waiting.extend(groups)
+        self._pump_prefills()                  # the prompt's kernels are queued first: everything below is off their path
         with self._on_engine_stream():
             for s in streams:
-                self._write_row(s)
-                s.active = False
-        self._prefill_waiting.extend(groups)
-        self._pump_prefills()
+                self._write_row(s)             # (read when the stream is switched on, at the start of a later step)
 
     @contextlib.contextmanager
     def _on_engine_stream(self):
@@ -262,6 +264,7 @@ class FrameEngine:
         tab = st.h("tables")[:self.max_streams * mb].view(self.max_streams, mb)
         tab[row].fill_(0)
         tab[row, :s.need] = torch.tensor(s.seq.block_table, dtype=torch.int32)
+        s.row_written = True
 
     def _prefill_now(self, streams: list[Stream]):
         """Prefills the prompts of freshly reserved streams between two frames, packed into as few runner steps as the
@@ -326,7 +329,7 @@ class FrameEngine:
                     ready.synchronize()
                     self._prefill_running = None
                     continue
-                if not (block or ready.query()):
+                if not (block or ready.query()) or not all(s.row_written for s in live):
                     return
                 with self._on_engine_stream():
                     self.tr.stream.wait_event(ready)
