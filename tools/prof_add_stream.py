@@ -31,12 +31,15 @@ def main():
                      num_kvcache_blocks=32, max_num_batched_tokens=4096, codec_eos=None)
     sp = (SamplingParams(temperature=1.0, max_tokens=1, do_sample=False), SamplingParams(temperature=0.9, max_tokens=17, do_sample=False))
     prof = cProfile.Profile()
-    for L in (16, 48, 200, 200, 48, 16):
+    for L in (16, 16, 48, 200, 200, 48, 16):
         x = torch.randn(L, 2048, device=dev) * 0.5
         t = torch.randn(126, 2048, device=dev) * 0.1
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        prof.enable()
+        first = not getattr(main, 'warm', False)
+        main.warm = True
+        if not first:
+            prof.enable()
         (sid,) = fe.add_streams([dict(prompt_embeds=x, text_adds=t, max_frames=125, talker_sampling=sp[0], predictor_sampling=sp[1])], wait=False)
         prof.disable()
         t1 = time.perf_counter()
@@ -46,7 +49,7 @@ def main():
         fe.step()
         fe.remove_stream(sid)
         torch.cuda.synchronize()
-    pstats.Stats(prof).sort_stats("cumulative").print_stats(28)
+    pstats.Stats(prof).sort_stats("tottime").print_stats(22)
 
 
 if __name__ == "__main__":
