@@ -125,6 +125,9 @@ class FrameEngine:
         self._talker_s = 0.0
         self._pred_meta_bs = None
         self._next_sid = 0
+        # values of per-row metadata writes on their way to the device (_sync_row_to_device)
+        self._ring = torch.zeros(512, (4 + self.tr.max_blocks_per_seq + 1) & ~1, dtype=torch.int32).pin_memory()     # (8-byte rows)
+        self._ring_next = 0
         self.stream = self.tr.stream
         # Run every kernel of the frame once, eagerly, with all rows inactive (context 0, slot -1:
         # nothing is stored, nothing advances) so that no code object is first loaded under capture.
@@ -242,8 +245,8 @@ class FrameEngine:
         return s
 
     def _write_row(self, s: Stream):
-        """The row's per-stream state (on the engine's stream): text additions, sampling, frame counter, the talker's
-        decode metadata for the token that WILL be fed next."""
+        """The row's per-stream state (on the engine's stream): text additions, sampling, frame counter, context limit
+        (the talker's decode metadata follows when the stream is switched on, _sync_row_to_device)."""
         row, F, text_adds = s.row, s.n_text, s.text_adds
         self.text_add[row, :F].copy_(text_adds[:F].to(self.device, torch.float32), non_blocking=True)
         if F < self.max_text_frames:
@@ -255,15 +258,6 @@ class FrameEngine:
         self.temps_p[row] = s.psp.temperature
         self.greedy_t[row] = 0 if s.tsp.do_sample else 1
         self.greedy_p[row] = 0 if s.psp.do_sample else 1
-        # prepare_decode_talker semantics for a sequence of prompt + first code
-        st, mb = self.tr.dstage, self.tr.max_blocks_per_seq
-        n = s.prompt_len + 1
-        st.h("positions")[row] = n - 1                     # advance_decode adds 1 before the first decode
-        st.h("ctx")[row] = n - 1
-        st.h("slots")[row] = -1
-        tab = st.h("tables")[:self.max_streams * mb].view(self.max_streams, mb)
-        tab[row].fill_(0)
-        tab[row, :s.need] = torch.tensor(s.seq.block_table, dtype=torch.int32)
         s.row_written = True
 
     def _prefill_now(self, streams: list[Stream]):
@@ -285,7 +279,7 @@ class FrameEngine:
                     self._write_row(s)
                     self.cur_hidden[s.row].copy_(hidden[i])
                     self.cur_token[s.row] = toks[i]
-                    self._sync_row_to_device(s.row)
+                    self._sync_row_to_device(s.row, s)
             self._fence.record(self.tr.stream)
 
     # ---------------------------------------------------------------- prefill beside the frames
@@ -336,7 +330,7 @@ class FrameEngine:
                     for s in live:
                         self.cur_hidden[s.row].copy_(self.pend_hidden[s.row], non_blocking=True)
                         self.cur_token[s.row:s.row + 1].copy_(self.pend_token[s.row:s.row + 1], non_blocking=True)
-                        self._sync_row_to_device(s.row)
+                        self._sync_row_to_device(s.row, s)
                         s.active = True
                 self._prefill_running = None
                 block = False
@@ -355,11 +349,28 @@ class FrameEngine:
             self._pump_prefills(block=True)
         return True
 
-    def _sync_row_to_device(self, row):
+    def _sync_row_to_device(self, row, s: Stream | None):
+        """The talker's decode metadata of a row, written on the current stream: a stream that is switched on gets
+        prepare_decode_talker's values for prompt + first code, one step back (advance_decode adds 1 before the first
+        decode step); a row that is handed back gets context 0 / slot -1 (nothing is stored, nothing advances).
+        Every call takes a fresh slot of a pinned ring for its values.  (A copy from pinned memory may read its source
+        only when it executes, behind whatever frames are queued; with one staging entry per row the host could by then
+        have written the row's next tenant into it, whose context length would switch the row on before its prefill.
+        The runtime in use was not seen to read that late for copies this small, but nothing here should depend on it;
+        a slot is reused after 512 calls, several seconds of serving later.)"""
         st, mb = self.tr.dstage, self.tr.max_blocks_per_seq
-        for name in ("positions", "ctx", "slots"):
-            st.d(name)[row:row + 1].copy_(st.h(name)[row:row + 1], non_blocking=True)
-        st.d("tables")[row * mb:(row + 1) * mb].copy_(st.h("tables")[row * mb:(row + 1) * mb], non_blocking=True)
+        k = self._ring_next
+        self._ring_next = (k + 1) % self._ring.shape[0]
+        slot = self._ring[k]                                 # int32 [4 + mb]: position (int64 as two words), ctx, slot, table
+        n1 = 0 if s is None else s.prompt_len                # = len(prompt + first code) - 1
+        slot[0], slot[1], slot[2], slot[3] = n1, 0, n1, -1
+        for j in range(mb):
+            slot[4 + j] = s.seq.block_table[j] if (s is not None and j < s.need) else 0
+        st.d("positions")[row:row + 1].copy_(slot[0:2].view(torch.int64), non_blocking=True)
+        st.d("ctx")[row:row + 1].copy_(slot[2:3], non_blocking=True)
+        st.d("slots")[row:row + 1].copy_(slot[3:4], non_blocking=True)
+        if s is not None:
+            st.d("tables")[row * mb:(row + 1) * mb].copy_(slot[4:4 + mb], non_blocking=True)
 
     def remove_stream(self, sid: str):
         s = self.streams.pop(sid, None)
@@ -369,11 +380,8 @@ class FrameEngine:
             s.ready.synchronize()                    # its prefill still writes the KV blocks that are about to be freed
         self._prefill_waiting = [g for g in ([w for w in grp if w is not s] for grp in self._prefill_waiting) if g]
         self.rows[s.row] = None
-        st = self.tr.dstage
         with self._on_engine_stream():
-            st.h("ctx")[s.row] = 0
-            st.h("slots")[s.row] = -1
-            self._sync_row_to_device(s.row)
+            self._sync_row_to_device(s.row, None)
             self._fence.record(self.tr.stream)       # whoever gets the row or the blocks next starts behind this
         self.talker.scheduler.block_manager.deallocate(s.seq)
 

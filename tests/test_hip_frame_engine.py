@@ -445,3 +445,54 @@ def test_prompts_admitted_together_are_prefilled_packed_and_give_the_same_ids(tm
     out = fe.run_frames(5)
     assert out[:, rows["long4"]].tolist() == want[4] and out[:, rows["long5"]].tolist() == want[5]
     fe.exit()
+
+
+def test_a_row_taken_over_while_its_last_talker_step_runs_starts_at_frame_zero(tmp_path):
+    """1.7B shapes (a talker step takes a millisecond): stream A ends with its frame budget and, before the talker step
+    that closed its last frame has finished on the GPU, request C takes over A's row (add_stream(wait=False), as a
+    serving loop does from the engine's hook; frames go on beside C's prefill).  Handing the row back and switching C
+    on both write the row's decode metadata behind the queued frames: the row must stay switched off in between (its
+    frame index still 0 at C's first frame, i.e. C reads its own text rows from the first), whatever the moment the
+    device sees those writes.  C's and the bystander B's ids must equal their runs alone."""
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    from nano_qwen3tts_vllm.utils import synthetic
+    cfg = synthetic.make_config("1.7B")
+    sd = synthetic.make_state_dict(cfg, seed=31, norm_jitter=0.1, embed_std=0.05, head_sharp=1.0, head_std=0.05)
+    tw, pw = synthetic.split_state_dict(sd)
+    del sd
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    H = cfg["talker_config"]["hidden_size"]
+    gen = torch.Generator().manual_seed(9)
+    prompts = [torch.randn(L, H, generator=gen) * 0.5 for L in (7, 12, 10)]
+    texts = [torch.randn(8, H, generator=gen) * 0.6 for _ in prompts]        # a frame's text row matters to its ids
+    kw = dict(max_streams=2, max_text_frames=8, talker_weights=tw, predictor_weights=pw, num_kvcache_blocks=4,
+              max_num_batched_tokens=1024, codec_eos=None)
+    sp = dict(talker_sampling=greedy(1), predictor_sampling=greedy(17, 0.9))
+
+    def solo(i, n):
+        fe = FrameEngine(str(tmp_path), **kw)
+        fe.add_stream(prompts[i], texts[i], max_frames=n, **sp)
+        out = fe.run_frames(n)[:, 0].tolist()
+        fe.exit()
+        return out
+
+    want_b, want_c = solo(1, 7), solo(2, 4)
+    for attempt in range(2):
+        fe = FrameEngine(str(tmp_path), **kw)
+        fe.join_prefills = False                              # frames go on while C's prompt is prefilled beside them
+        a = fe.add_stream(prompts[0], texts[0], max_frames=2, **sp)
+        b = fe.add_stream(prompts[1], texts[1], max_frames=7, **sp)
+        got = {a: [], b: []}
+        for _ in range(2):
+            for sid, fr in fe.step().items():
+                got[sid].append(fr)
+        assert a not in fe.streams                            # A has ended; the talker step of its last frame is in flight
+        c = fe.add_stream(prompts[2], texts[2], max_frames=4, wait=False, **sp)
+        assert fe.streams[c].row == 0
+        got[c] = []
+        while fe.streams:
+            for sid, fr in fe.step().items():
+                got[sid].append(fr)
+        fe.exit()
+        assert got[b] == want_b, attempt
+        assert got[c] == want_c, attempt
