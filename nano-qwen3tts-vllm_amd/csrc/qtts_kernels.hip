@@ -1449,7 +1449,7 @@ extern "C" int qtts_store_kvcache(const void *k, int ldk, const void *v, int ldv
 // ------------------------------------------------------------------ paged attention
 #define ATT_SPLIT 128   // tokens per workgroup
 static_assert(QTTS_KV_BLOCK % ATT_SPLIT == 0, "a workgroup's tokens must lie in one KV block");
-// grid (rows, Hkv, nsplit); 256 threads = 16 groups of 16 lanes; a group owns
+// grid (Hkv, rows, nsplit); 256 threads = 16 groups of 16 lanes; a group owns
 // tokens split*128 + i*16 + grp, i < 8; a lane owns 8 of the 128 head dims.
 template <int G>
 __global__ __launch_bounds__(256) void paged_attn_kernel(
@@ -1460,7 +1460,10 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(
     __shared__ float sm_acc[16][G][128];
     __shared__ float sm_m[16][G];
     __shared__ float sm_l[16][G];
-    const int row = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
+    // grid (Hkv, rows, splits): workgroups are dealt to the XCDs in turn along x, so with 8 KV heads every workgroup of
+    // head h runs on XCD h and that head's K/V rows, which all rows of a sequence read, are fetched into one L2 once
+    // instead of into eight
+    const int kvh = blockIdx.x, row = blockIdx.y, split = blockIdx.z;
     const int ctx = context_lens[row];
     const int Hq = Hkv * G;
     const int t0 = split * ATT_SPLIT;
@@ -1589,7 +1592,7 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------ prompt attention on MFMA
-// Rows of a prompt, 16 at a time: grid (row tiles, Hkv), 8 waves per workgroup; wave (tg, h) owns query head
+// Rows of a prompt, 16 at a time: grid (Hkv, row tiles), 8 waves per workgroup; wave (tg, h) owns query head
 // kvh*G + h of the tile's 16 rows and every (8/G)-th 32-token step of the context (a step is a chain of dependent
 // round trips, so the steps of a context run side by side rather than one after the other), the token groups merge
 // through LDS at the end (no partials in global memory, no combine launch).
@@ -1619,8 +1622,11 @@ __global__ __launch_bounds__(512) void prefill_attn_mfma_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, r = lane & 15;
     const int tg = wave / G, h = wave % G;
-    const int kvh = blockIdx.y, hq = kvh * G + h;
-    const int m = blockIdx.x * 16 + r;
+    // grid (Hkv, row tiles): the row tiles of a KV head share an XCD and its L2 (see paged_attn_kernel); the last
+    // row tiles of a prompt walk the most tokens and are dispatched first, so that no long workgroup starts when the
+    // others are about to end
+    const int kvh = blockIdx.x, hq = kvh * G + h;
+    const int m = ((int)gridDim.y - 1 - (int)blockIdx.y) * 16 + r;
     const bool rvalid = m < N;
     const int mc = rvalid ? m : N - 1;
     const int ctx = rvalid ? context_lens[mc] : 0;
@@ -1804,7 +1810,7 @@ static int paged_attention_impl(const void *q, int ldq, const void *k_cache, con
     if (row_seq && N >= g_mfma_attn_rows && (G == 1 || G == 2)) {
         // several rows per sequence (a prompt): 16 rows per workgroup on MFMA.  Below about a hundred rows the
         // per-row kernel is faster (a 48-token prompt: 6.6 against 10 us per layer; 200 tokens: 25 against 14 us)
-        const dim3 grid((N + 15) / 16, Hkv);
+        const dim3 grid(Hkv, (N + 15) / 16);
         const size_t shmem = (size_t)8 * PA_WAVE_LDS;                  // eight waves, whatever G is
         const void *kern = G == 1 ? reinterpret_cast<const void *>(&prefill_attn_mfma_kernel<1>)
                                   : reinterpret_cast<const void *>(&prefill_attn_mfma_kernel<2>);
@@ -1822,9 +1828,10 @@ static int paged_attention_impl(const void *q, int ldq, const void *k_cache, con
     }
     const int ns = attn_nsplit(max_context);
     QCHECK(ns == 1 || workspace, "paged_attention: workspace required for contexts > %d", ATT_SPLIT);
+    QCHECK(N <= 65535, "paged_attention: at most 65535 rows per launch (got %d)", N);
     float *part_o = (float *)workspace;
     float *part_ml = part_o ? part_o + (size_t)N * Hq * ns * 128 : nullptr;
-    dim3 grid(N, Hkv, ns);
+    dim3 grid(Hkv, N, ns);
 #define QA(G_) case G_: hipLaunchKernelGGL((paged_attn_kernel<G_>), grid, dim3(256), 0, s, (const bf16_t *)q, ldq, \
         (const bf16_t *)k_cache, (const bf16_t *)v_cache, block_tables, max_blocks, row_seq, context_lens, scale, \
         (bf16_t *)out, ldo, Hkv, part_o, part_ml, ns, opks); break;

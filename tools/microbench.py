@@ -301,6 +301,32 @@ def frame():
         print(f"{name:18s} {us:8.1f} us per graph launch", flush=True)
 
 
+def decode_eager():
+    """The talker's decode step (28 layers) and the predictor's burst at 8 streams, launched eagerly a few times (no
+    graph: counter collection under the profiler is per launch), contexts of QTTS_FRAME_PROMPT + a few tokens."""
+    import json, tempfile
+    sys.path.insert(0, ROOT)
+    import bench
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    from nano_qwen3tts_vllm.sampling_params import SamplingParams
+    from nano_qwen3tts_vllm.utils import synthetic
+    cfg = synthetic.make_config("1.7B")
+    tw, pw = bench.make_weights(cfg, dev)
+    d = tempfile.mkdtemp()
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+    B = 8
+    fe = FrameEngine(d, max_streams=B, max_text_frames=64, talker_weights=tw, predictor_weights=pw,
+                     num_kvcache_blocks=4 * B, max_num_batched_tokens=4096, codec_eos=None, enforce_eager=True)
+    sp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
+    plen = int(os.environ.get("QTTS_FRAME_PROMPT", "300"))
+    for i in range(B):
+        fe.add_stream(torch.randn(plen, 2048, device=dev) * 0.5, torch.randn(8, 2048, device=dev) * 0.1, 60, sp,
+                      SamplingParams(temperature=0.9, max_tokens=17, do_sample=False))
+    fe.run_frames(int(os.environ.get("QTTS_FRAMES", "6")))
+    torch.cuda.synchronize()
+    print("done", flush=True)
+
+
 def rows():
     """Prompt GEMMs at the talker's shapes: rows x (cold weights: 28 different matrices in turn | one hot matrix)."""
     H, I = 2048, 6144
@@ -452,4 +478,4 @@ def prefill():
 
 
 if __name__ == "__main__":
-    {"prefill": prefill, "prefill_batch": prefill_batch, "rows": rows, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
+    {"prefill": prefill, "prefill_batch": prefill_batch, "decode_eager": decode_eager, "rows": rows, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
