@@ -277,11 +277,16 @@ def test_frame_loop_ids_match_reference_fixture(setup):
     pred.exit()
 
 
-@pytest.mark.parametrize("size,weights,prompt_lens", [("1.7B", "bf16", (9, 40)), ("0.6B", "bf16", (9, 40)),
-                                                      ("1.7B", "bf16", (130, 270)), ("1.7B", "fp8", (130, 270)),
-                                                      ("1.7B", "bf16", (5, 9, 16, 33, 64, 100, 17, 40)),
-                                                      ("1.7B", "bf16", (7, 12, 20, 33, 48, 5, 9, 70, 16, 25, 31, 64))])
-def test_full_size_frames_match_oracle(size, weights, prompt_lens, tmp_path, monkeypatch):
+ICL8 = (90, 130, 110, 150, 100, 140, 120, 170)
+
+
+@pytest.mark.parametrize("size,weights,prompt_lens,admission",
+                         [("1.7B", "bf16", (9, 40), "each"), ("0.6B", "bf16", (9, 40), "each"),
+                          ("1.7B", "bf16", (130, 270), "each"), ("1.7B", "fp8", (130, 270), "each"),
+                          ("1.7B", "bf16", (5, 9, 16, 33, 64, 100, 17, 40), "each"),
+                          ("1.7B", "bf16", (7, 12, 20, 33, 48, 5, 9, 70, 16, 25, 31, 64), "each"),
+                          ("1.7B", "fp8", ICL8, "packed"), ("1.7B", "bf16", (33, 200, 70), "beside")])
+def test_full_size_frames_match_oracle(size, weights, prompt_lens, admission, tmp_path, monkeypatch):
     """The released checkpoints' shapes (28 + 5 layers; 1.7B: hidden 2048 with the 2048 -> 1024 projection in front of
     the predictor, 0.6B: hidden 1024, no projection), random weights with spread-out heads, 2 streams (prompts of 9
     and 40 tokens) x 3 frames through the frame engine, against the CPU oracle on the same weights and the same
@@ -297,7 +302,10 @@ def test_full_size_frames_match_oracle(size, weights, prompt_lens, tmp_path, mon
     `weights="fp8"` the engine stores the layer GEMM weights as e4m3 with a power-of-two row scale and the oracle runs
     on exactly those dequantised weights, so the same bounds apply (the quantisation itself is not judged here).
     Eight streams are the benchmark's batch (one 16-row tile, half of it streams); twelve use the 16-row graphs with
-    every MFMA column a row of its own and four rows idle."""
+    every MFMA column a row of its own and four rows idle.
+    admission="packed": eight voice-clone-length prompts (1010 rows together) admitted at once go through ONE packed
+    prefill (add_streams) with fp8 weights; "beside": three prompts admitted without waiting are prefilled packed on the
+    second HIP stream through the twin decoder and join the batch at the next frame."""
     from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
     monkeypatch.setenv("QTTS_WEIGHT_DTYPE", weights)
     cfg = synthetic.make_config(size)
@@ -312,10 +320,19 @@ def test_full_size_frames_match_oracle(size, weights, prompt_lens, tmp_path, mon
     fe = FrameEngine(str(tmp_path), max_streams=S, max_text_frames=NF + 1, talker_weights=tw, predictor_weights=pw,
                      num_kvcache_blocks=max(4, S), max_num_batched_tokens=1024, codec_eos=None)
     t_logits, p_logits = [[] for _ in range(S)], []
-    for i in range(S):
-        fe.add_stream(prompts[i], text_adds[i], max_frames=NF, talker_sampling=greedy_sp(1), predictor_sampling=greedy_sp(17))
+    if admission == "each":
+        for i in range(S):
+            fe.add_stream(prompts[i], text_adds[i], max_frames=NF, talker_sampling=greedy_sp(1), predictor_sampling=greedy_sp(17))
+            torch.cuda.synchronize()
+            t_logits[i].append(fe.tr.logits[0].float().cpu())      # the prefill's logits: first code of frame 0
+    else:
+        reqs = [dict(prompt_embeds=prompts[i], text_adds=text_adds[i], max_frames=NF, talker_sampling=greedy_sp(1),
+                     predictor_sampling=greedy_sp(17), sid=f"s{i}") for i in range(S)]
+        assert fe.add_streams(reqs, wait=admission == "packed") == [f"s{i}" for i in range(S)]
         torch.cuda.synchronize()
-        t_logits[i].append(fe.tr.logits[0].float().cpu())          # the prefill's logits: first code of frame 0
+        assert [fe.streams[f"s{i}"].row for i in range(S)] == list(range(S))
+        for i in range(S):
+            t_logits[i].append((fe.tr.logits if admission == "packed" else fe.tr.pre_logits)[i].float().cpu())
     got = []
     for f in range(NF):
         got.append(fe.run_frames(1)[0, :S])
@@ -336,8 +353,8 @@ def test_full_size_frames_match_oracle(size, weights, prompt_lens, tmp_path, mon
     gp = torch.stack(p_logits, 1)                                   # [S,NF,15,Vp]
     for name, mine, ref, alt in (("talker", gt, r["t_logits"], ra["t_logits"]), ("predictor", gp, r["p_logits"], ra["p_logits"])):
         d, noise = ulp_distance(mine, ref), ulp_distance(alt, ref)
-        print(f"[logits] {size} {weights} prompts {prompt_lens} {name}: HIP within {float(d.max()):.1f} bf16 steps of the oracle (mean {float(d.mean()):.3f}); the "
+        print(f"[logits] {size} {weights} prompts {prompt_lens} ({admission}) {name}: HIP within {float(d.max()):.1f} bf16 steps of the oracle (mean {float(d.mean()):.3f}); the "
               f"oracle with re-ordered sums within {float(noise.max()):.1f} (mean {float(noise.mean()):.3f})")
         assert float(d.mean()) <= 1.5 * float(noise.mean()) + 0.02 and float(d.max()) <= 2.0 * float(noise.max()) + 2.0
-    check_frames(got, tw, tc, pw, pc, prompts, text_adds, f"frame engine at {size} shapes, {weights} weights, prompts {prompt_lens}", tol_ulps=8.0, min_binding=0.7,
+    check_frames(got, tw, tc, pw, pc, prompts, text_adds, f"frame engine at {size} shapes, {weights} weights, prompts {prompt_lens} admitted {admission}", tol_ulps=8.0, min_binding=0.7,
                  max_unacceptable=2, oracle_result=r)

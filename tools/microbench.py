@@ -256,6 +256,41 @@ def dominant():
         print(f"per launch: eager {eager:.2f} us, inside one graph {graph:.2f} us", flush=True)
 
 
+def mall():
+    """Decode GEMMs at the talker's shapes (8 rows) cycling through 1, 2, 4 or 28 weight matrices inside one graph:
+    how much faster a launch is when its weights are still in the memory-side cache (256 MB) or in L2 (8 x 4 MB)."""
+    B, H, I = 8, 2048, 6144
+    x = torch.randn(B, H, device=dev).bfloat16()
+    xi = torch.randn(B, I, device=dev).bfloat16()
+    nw = torch.ones(H, device=dev).bfloat16()
+    res = torch.randn(B, H, device=dev).bfloat16()
+    for name, N, K in (("gate/up", 2 * I, H), ("down", H, I), ("qkv", 4096, H), ("o", H, H)):
+        line = f"{name:8s} {N * K * 2 / 1e6:5.1f} MB:"
+        for nbuf in (1, 2, 4, 8, 28):
+            ws = [torch.randn(N * K, device=dev).bfloat16() * 0.02 for _ in range(nbuf)]
+            out = torch.empty(B, N, dtype=torch.bfloat16, device=dev)
+
+            def run():
+                for i in range(28):
+                    w = ws[i % nbuf]
+                    if name == "gate/up":
+                        hip.linear_swiglu(x, w, I, norm_w=nw, out=out)
+                    elif name == "down":
+                        hip.linear_fused(xi, w, N, K=K, residual=res, out=out)
+                    elif name == "qkv":
+                        hip.linear_fused(x, w, N, K=K, norm_w=nw, out=out)
+                    else:
+                        hip.linear_fused(x, w, N, K=K, residual=res, out=out)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                run()
+                g = hip.Graph.capture(run)
+            us = timed(lambda: g.launch(), 28)
+            line += f"  {nbuf:2d} bufs {us:6.2f} us ({N * K * 2 / us / 1e6:5.2f} TB/s)"
+            del ws
+        print(line, flush=True)
+
+
 def frame():
     import json, tempfile
     sys.path.insert(0, ROOT)
@@ -478,4 +513,4 @@ def prefill():
 
 
 if __name__ == "__main__":
-    {"prefill": prefill, "prefill_batch": prefill_batch, "decode_eager": decode_eager, "rows": rows, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
+    {"prefill": prefill, "prefill_batch": prefill_batch, "decode_eager": decode_eager, "rows": rows, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "mall": mall, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
