@@ -285,7 +285,8 @@ ICL8 = (90, 130, 110, 150, 100, 140, 120, 170)
                           ("1.7B", "bf16", (130, 270), "each"), ("1.7B", "fp8", (130, 270), "each"),
                           ("1.7B", "bf16", (5, 9, 16, 33, 64, 100, 17, 40), "each"),
                           ("1.7B", "bf16", (7, 12, 20, 33, 48, 5, 9, 70, 16, 25, 31, 64), "each"),
-                          ("1.7B", "fp8", ICL8, "packed"), ("1.7B", "bf16", (33, 200, 70), "beside")])
+                          ("1.7B", "fp8", ICL8, "packed"), ("1.7B", "bf16", (33, 200, 70), "beside"),
+                          ("1.7B", "bf16", (1020,), "each")])
 def test_full_size_frames_match_oracle(size, weights, prompt_lens, admission, tmp_path, monkeypatch):
     """The released checkpoints' shapes (28 + 5 layers; 1.7B: hidden 2048 with the 2048 -> 1024 projection in front of
     the predictor, 0.6B: hidden 1024, no projection), random weights with spread-out heads, 2 streams (prompts of 9
@@ -305,7 +306,10 @@ def test_full_size_frames_match_oracle(size, weights, prompt_lens, admission, tm
     every MFMA column a row of its own and four rows idle.
     admission="packed": eight voice-clone-length prompts (1010 rows together) admitted at once go through ONE packed
     prefill (add_streams) with fp8 weights; "beside": three prompts admitted without waiting are prefilled packed on the
-    second HIP stream through the twin decoder and join the batch at the next frame."""
+    second HIP stream through the twin decoder and join the batch at the next frame.
+    A prompt of 1020 tokens + 3 frames + the step that closes the last one fill the model's 1024 positions exactly: the
+    longest prompt the engine admits (64 row tiles through the prompt attention, four KV blocks), decode attention over
+    eight 128-token splits with the last-arriver merge, the last RoPE table row."""
     from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
     monkeypatch.setenv("QTTS_WEIGHT_DTYPE", weights)
     cfg = synthetic.make_config(size)
