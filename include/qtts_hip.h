@@ -222,7 +222,9 @@ int qtts_embedding_gather(const void *table, const int64_t *ids, void *out, int 
  * where code_0 = token0[b], code_c = pred_tokens[(c-1)*ldp + b], and text_add_b is
  * the fp32 row text_add + b*ld_text + frame_idx[b]*H (frame_idx NULL: row 0) — the
  * trailing text hidden or tts pad embedding the API adds each frame.  The 16 ids
- * are also written to codes[b*16 + c] when codes != NULL. */
+ * are also written to codes[b*16 + c] when codes != NULL.  qtts_frame_glue reads
+ * and writes 16 bytes at a time: H % 8 == 0, ld_text % 4 == 0, every table, text_add
+ * and next 16-byte aligned. */
 int qtts_predictor_input(const void *hidden, const void *talker_emb, const int64_t *token0,
                          void *pred_in, int B, int H, int vocab, qtts_stream_t stream);
 int qtts_frame_glue(const void *talker_emb, const void *const *pred_emb_tables /* device array of 15 */,

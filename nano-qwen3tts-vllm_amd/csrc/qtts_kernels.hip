@@ -2868,15 +2868,30 @@ __global__ __launch_bounds__(256) void frame_glue_kernel(const bf16_t *__restric
     }
     __syncthreads();
     const float *ta = text_add + (size_t)b * ld_text + (size_t)fidx * H;
-    for (int d = threadIdx.x; d < H; d += 256) {
-        float v[16];
+    // eight columns per thread, 16 bytes per table row: a hidden size of 2048 is one pass with all 18 requests of a
+    // thread in flight together (H % 8 == 0 and 16-byte aligned rows are checked on the host)
+    for (int d = 8 * threadIdx.x; d < H; d += 8 * 256) {
+        Frag v[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = bf2f(rows[c][d]);
-        const float tv_ = ta[d];
-        float s = v[0];
+        for (int c = 0; c < 16; ++c) v[c].u = *reinterpret_cast<const uint4 *>(rows[c] + d);
+        const float4_t t0 = *reinterpret_cast<const float4_t *>(ta + d), t1 = *reinterpret_cast<const float4_t *>(ta + d + 4);
+        float s[8];
 #pragma unroll
-        for (int c = 1; c < 16; ++c) s += v[c];
-        next[(size_t)b * H + d] = f2bf(s + tv_);
+        for (int c = 0; c < 16; ++c) {
+            const uint32_t w4[4] = {v[c].u.x, v[c].u.y, v[c].u.z, v[c].u.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float lo, hi;
+                unpack2(w4[j], lo, hi);
+                s[2 * j] = c == 0 ? lo : s[2 * j] + lo;            // table 0 first, then 1..15, the text row last
+                s[2 * j + 1] = c == 0 ? hi : s[2 * j + 1] + hi;
+            }
+        }
+        const float tx[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        uint32_t o4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o4[j] = pack2(s[2 * j] + tx[2 * j], s[2 * j + 1] + tx[2 * j + 1]);
+        *reinterpret_cast<uint4 *>(next + (size_t)b * H + d) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
     }
 }
 
@@ -2886,6 +2901,8 @@ extern "C" int qtts_frame_glue(const void *talker_emb, const void *const *pred_e
                                int pred_vocab, qtts_stream_t stream) {
     QCHECK(talker_emb && pred_emb_tables && token0 && pred_tokens && text_add && next && B > 0 && H > 0 && ldp >= B,
            "frame_glue: bad arguments");
+    QCHECK(H % 8 == 0 && ld_text % 4 == 0 && ((uintptr_t)talker_emb | (uintptr_t)text_add | (uintptr_t)next) % 16 == 0,
+           "frame_glue: hidden size must be a multiple of 8, rows 16-byte aligned");
     hipLaunchKernelGGL(frame_glue_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)talker_emb,
                        (const bf16_t *const *)pred_emb_tables, token0, pred_tokens, ldp, text_add, ld_text, frame_idx,
                        (bf16_t *)next, codes, H, talker_vocab, pred_vocab);
