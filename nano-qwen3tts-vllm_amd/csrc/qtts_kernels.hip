@@ -268,7 +268,8 @@ struct LinArgs {
     // order (act_index) instead of row-major
     int xpacked = 0, opks = 0, nnpks = 0;
     int dbg;      // bit0: tuning experiment (every tile reads weight tile 0); bit3: `ids` select the residual rows, not the
-                  // x rows; bits 4-5: log2 of the workgroups per tile; bits 8+: row-tile count of a prefill launch
+                  // x rows; bits 4-5: log2 of the workgroups per tile; bit 7: x in fragment order (one row tile);
+                  // bits 8+: row-tile count of a prefill launch
 };
 
 // 16 fp8 (e4m3, OCP) values -> two bf16 fragments, exactly (every e4m3 value is a bf16 value).  Bytes 0..7 belong
@@ -301,6 +302,7 @@ struct LinTail {
     bf16_t *xnorm_out; int ldxn;
     bf16_t *out; int ldo;
     const float *wscale;  // fp8 weights: one power-of-two scale per packed weight row
+    int opks;             // EPI 1: > 0 = `out` in fragment order with this many k-steps (the next GEMM's K / 32)
 #ifdef QTTS_TUNING
     long long *trace;     // 4 timestamps per workgroup
 #endif
@@ -427,6 +429,15 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
     if (EPI == 0)
         rres = *(((p.dbg & 8) && p.ids) ? p.ids + (mvalid ? m : 0) : reinterpret_cast<const int64_t *>(p.x));
     const bf16_t *xp = p.x + xrow + 32 * ks0 + 8 * g;
+    // bit 7 of dbg: x is one 16-row tile in fragment order (act_index) - a request is one contiguous KiB instead of
+    // 64 bytes from each of 16 rows (plain prologue without shared lanes only: decode steps of 9..16 rows)
+    int xstep = 32;
+    if constexpr (!H8 && PRO == 0) {
+        if (p.dbg & 128) {
+            xp = p.x + ((size_t)ks0 * 64 + lane) * 8;
+            xstep = 512;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < KSW; ++i) {
         if (PRO == 2) {
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
             }
             xb[i].u = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         } else if (!H8) {
-            xb[i].u = *reinterpret_cast<const uint4 *>(xp + 32 * i);
+            xb[i].u = *reinterpret_cast<const uint4 *>(xp + xstep * i);
         } else if (i % 2 == 0) {
             xb[i].u = *reinterpret_cast<const uint4 *>(xp + 32 * (i + hi));
         }
@@ -632,7 +643,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
                             const float sv = rbf(silu_f(gv));
                             v[j] = sv * rbf(ups[j]);
                         }
-                        *reinterpret_cast<uint2 *>(p.out + (size_t)m * p.ldo + 8 * t + 4 * g) =
+                        *reinterpret_cast<uint2 *>(p.out + act_index(m, 8 * t + 4 * g, p.ldo, H8 ? 0 : tl.opks)) =
                             make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
                     }
                 }
@@ -988,6 +999,7 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
     }
 #endif
     tl.wscale = a.wscale;
+    tl.opks = a.opks;
     if constexpr (KSW % 2 == 0 && PRO != 2) {
         if (a.wscale) {
             // fp8 weights: the activation prologue is the bf16 kernels', shared lanes for at most 8 rows included
@@ -1166,7 +1178,11 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
         QLAUNCH();
         return QTTS_OK;
     }
-    if (a.xpacked || a.opks || a.nnpks) QFAIL(QTTS_ESTATE, "linear: activations in fragment order but the prompt GEMM does not take M=%d N=%d K=%d", a.M, a.N, a.K);
+    // One row tile of 9..16 rows (a decode step; up to 8 rows the lanes share the prologue instead): x of a plain
+    // prologue and the SwiGLU output may be in fragment order as well
+    const bool tile_frag = a.M > 8 && a.M <= 16 && !a.nnpks && (!a.xpacked || (pro == 0 && !a.ids)) && (!a.opks || silu_pairs);
+    if ((a.xpacked || a.opks || a.nnpks) && !tile_frag)
+        QFAIL(QTTS_ESTATE, "linear: activations in fragment order but neither the prompt GEMM nor the single-tile form takes M=%d N=%d K=%d", a.M, a.N, a.K);
     QCHECK(!a.next_nw, "linear: the fused norm of the result exists for the K-split prompt GEMM only");
     const int KS = a.K / 32;
     static const int ksws[] = {1, 2, 4, 6, 8, 12, 24};
@@ -1198,6 +1214,7 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     if (silu_pairs) QCHECK(KSW <= 12, "linear: the SwiGLU epilogue needs K <= 3072 (K=%d)", a.K);
     a.tiles_per_wg = tpw;
     a.dbg = g_dbg_linear & ~8;
+    if (a.xpacked) a.dbg |= 128;
     if (a.res_ids) {                                       // the kernel's id arguments carry the residual's row ids
         a.ids = a.res_ids; a.id_rows = a.res_id_rows; a.dbg |= 8;
     }
@@ -1884,6 +1901,7 @@ struct AttnFusedArgs {
     float *part_o, *part_ml; int nsplit;
     int *counters;
     const int64_t *row_ids; int id_rows;   // non-null: row r of the launch reads qkv row row_ids[r] (a table of rows)
+    int opks;                              // > 0: `out` in fragment order (act_index) with this many k-steps
 };
 
 // wv: the lane's 8 norm weights; cv, sv: its 8 cos / sin values (dims d and d + 64 share them)
@@ -1981,7 +1999,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
     vnew.u = *reinterpret_cast<const uint4 *>(rowp + (size_t)(Hq + Hkv + kvh) * 128 + 8 * l16);
     if (ctx <= 0) {
         if (split == 0)
-            for (int e = threadIdx.x; e < G * 128; e += NT) p.out[(size_t)row * p.ldo + (size_t)kvh * G * 128 + e] = 0;
+            for (int e = threadIdx.x; e < G * 128; e += NT) p.out[act_index(row, kvh * G * 128 + e, p.ldo, p.opks)] = 0;
         return;
     }
     if (t0 >= ctx) return;
@@ -2126,7 +2144,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
         }
         const int hq = kvh * G + h;
         if (direct) {
-            p.out[(size_t)row * p.ldo + (size_t)hq * 128 + d] = f2bf(o / L);
+            p.out[act_index(row, hq * 128 + d, p.ldo, p.opks)] = f2bf(o / L);
         } else {
             const size_t pi = ((size_t)row * Hq + hq) * a_nsplit + split;
             st_agent(p.part_o + pi * 128 + d, o);
@@ -2190,7 +2208,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
                 o += ld_agent(p.part_o + (p0 + s) * 128 + d) * wgt;
             }
         }
-        p.out[(size_t)row * p.ldo + (size_t)hq * 128 + d] = f2bf(o / L);
+        p.out[act_index(row, hq * 128 + d, p.ldo, p.opks)] = f2bf(o / L);
     }
     if (threadIdx.x == 0) __hip_atomic_store(p.counters + row * Hkv + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -2206,7 +2224,7 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
                                        void *v_cache, const int32_t *block_tables, int max_blocks,
                                        const int32_t *context_lens, int max_context, float scale, void *out,
                                        int ldo, int B, int Hq, int Hkv, void *partials, int *counters,
-                                       hipStream_t s, const int64_t *row_ids = nullptr, int id_rows = 0) {
+                                       hipStream_t s, const int64_t *row_ids = nullptr, int id_rows = 0, int opks = 0) {
     // uniform rows (no metadata arrays at all): row r = sequence r in KV block r, every row at context max_context
     const bool uniform = !positions && !slot_mapping && !block_tables && !context_lens;
     QCHECK(qkv && q_norm_w && k_norm_w && rope_cos && rope_sin && k_cache && v_cache && out &&
@@ -2235,6 +2253,8 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
     a.part_o = (float *)partials; a.part_ml = a.part_o ? a.part_o + (size_t)B * Hq * ns * 128 : nullptr; a.nsplit = ns;
     a.counters = counters;
     a.row_ids = row_ids; a.id_rows = id_rows;
+    QCHECK(opks == 0 || (B <= 16 && opks * 32 == Hq * 128), "attention_decode_fused: fragment-order output is one 16-row tile of Hq*128 columns");
+    a.opks = opks;
     dim3 grid(B, Hkv, ns);
     if (uniform) {
         // the context length travels in the max_blocks argument's place
@@ -2292,7 +2312,7 @@ __global__ __launch_bounds__(64) void attn_pair_kernel(const bf16_t *__restrict_
                                                        const bf16_t *__restrict__ kw, const bf16_t *__restrict__ cosT,
                                                        const bf16_t *__restrict__ sinT, int max_pos, float eps,
                                                        bf16_t *__restrict__ kc, bf16_t *__restrict__ vc, float scale,
-                                                       bf16_t *__restrict__ out, int ldo, int Hq, int Hkv) {
+                                                       bf16_t *__restrict__ out, int ldo, int Hq, int Hkv, int opks) {
     const int seq = blockIdx.x, kvh = blockIdx.y;
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     if (grp >= G) return;
@@ -2340,7 +2360,7 @@ __global__ __launch_bounds__(64) void attn_pair_kernel(const bf16_t *__restrict_
     for (int j = 0; j < 8; ++j) x[j] = bf2f(fq.h[j]);
     norm_rope8(x, qwv, cv[1], sv[1], eps, l16, q1);
     const int hq = kvh * G + grp;
-    *reinterpret_cast<uint4 *>(out + (size_t)(2 * seq) * ldo + (size_t)hq * 128 + 8 * l16) = vb[0].u;
+    *reinterpret_cast<uint4 *>(out + act_index(2 * seq, hq * 128 + 8 * l16, ldo, opks)) = vb[0].u;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -2359,22 +2379,23 @@ __global__ __launch_bounds__(64) void attn_pair_kernel(const bf16_t *__restrict_
         acc += p1 * bf2f(vb[1].h[j]);
         o.h[j] = f2bf(acc / L);
     }
-    *reinterpret_cast<uint4 *>(out + (size_t)(2 * seq + 1) * ldo + (size_t)hq * 128 + 8 * l16) = o.u;
+    *reinterpret_cast<uint4 *>(out + act_index(2 * seq + 1, hq * 128 + 8 * l16, ldo, opks)) = o.u;
 }
 
 static int attention_pairs_impl(const void *qkv, int ldqkv, const void *q_norm_w, const void *k_norm_w, float eps,
                                 const void *rope_cos, const void *rope_sin, int max_pos, const int64_t *positions,
                                 const int32_t *slot_mapping, void *k_cache, void *v_cache, float scale, void *out, int ldo,
-                                int N, int Hq, int Hkv, hipStream_t s) {
+                                int N, int Hq, int Hkv, hipStream_t s, int opks = 0) {
     QCHECK(qkv && q_norm_w && k_norm_w && rope_cos && rope_sin && positions && k_cache && v_cache && out,
            "attention_pairs: null pointer");
+    QCHECK(opks == 0 || (N <= 16 && opks * 32 == Hq * 128), "attention_pairs: fragment-order output is one 16-row tile of Hq*128 columns");
     QCHECK(N > 0 && N % 2 == 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && ldqkv % 8 == 0 && ldqkv >= (Hq + 2 * Hkv) * 128 &&
                ldo >= Hq * 128 && max_pos > 0, "attention_pairs: bad shape");
     dim3 grid(N / 2, Hkv);
 #define QPAIR(G_) hipLaunchKernelGGL((attn_pair_kernel<G_>), grid, dim3(64), 0, s, (const bf16_t *)qkv, ldqkv, positions, \
                                      slot_mapping, (const bf16_t *)q_norm_w, (const bf16_t *)k_norm_w, (const bf16_t *)rope_cos, \
                                      (const bf16_t *)rope_sin, max_pos, eps, (bf16_t *)k_cache, (bf16_t *)v_cache, scale, \
-                                     (bf16_t *)out, ldo, Hq, Hkv)
+                                     (bf16_t *)out, ldo, Hq, Hkv, opks)
     switch (Hq / Hkv) {
         case 1: QPAIR(1); break;
         case 2: QPAIR(2); break;
@@ -3221,6 +3242,15 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     const bf16_t *cur = (const bf16_t *)x;
     int rc;
     const bool decode = row_seq == nullptr;           // one row per sequence: fused norm/RoPE/store/attention
+    // Decode steps of 9..16 rows: every lane of a GEMM's activation requests carries a row of its own (no lanes to
+    // share the prologue with, as up to 8 rows), so the two activations a layer produces for a plain prologue -
+    // attention output for o_proj, SwiGLU output for down_proj - are handed over in fragment order: one contiguous
+    // KiB per request instead of 64 bytes from each of 16 rows.
+    // (The 2-position prompts of up to 8 fresh sequences are such a step too.)
+    const bool dfrag = decode && N > 8 && N <= 16 && m->ws_rows >= 16;
+    ActLayout lay_dx, lay_dgu;
+    lay_dx.xpacked = dfrag;
+    lay_dgu.opks = dfrag ? m->inter / 32 : 0;
     bool xn_ready = false, final_ready = false;       // a norm already applied by the producing launch
     for (int l = 0; l < m->n_layers; ++l) {
         const LayerW &L = m->layers[l];
@@ -3242,14 +3272,15 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         const bool tab0 = l == 0 && qkv0_rows;
         if (pairs) {
             if ((rc = attention_pairs_impl(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos, positions,
-                                           slot_mapping, kc, vc, scale, attn, Hq * 128, N, Hq, Hkv, (hipStream_t)stream)))
+                                           slot_mapping, kc, vc, scale, attn, Hq * 128, N, Hq, Hkv, (hipStream_t)stream,
+                                           dfrag ? Hq * 128 / 32 : 0)))
                 return rc;
         } else if (decode) {
             if ((rc = attention_decode_fused_impl(tab0 ? qkv0_rows : qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT,
                                                   m->max_pos, positions, slot_mapping, kc, vc, block_tables, max_blocks,
                                                   context_lens, max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws,
                                                   (int *)(m->ws + W.att_cnt), (hipStream_t)stream,
-                                                  tab0 ? x_ids : nullptr, x_id_rows))) return rc;
+                                                  tab0 ? x_ids : nullptr, x_id_rows, dfrag ? Hq * 128 / 32 : 0))) return rc;
         } else {
             if ((rc = qtts_qknorm_rope_store(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
                                              positions, slot_mapping, kc, vc, N, Hq, Hkv, stream))) return rc;
@@ -3260,7 +3291,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
             LayerEventScope ev(m, l, QTTS_LAUNCH_O_PROJ, stream);
             if ((rc = stack_linear(attn, Hq * 128, L.wo, L.s_o, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, nullptr, 0, stream,
                                    nullptr, nullptr, 0, nullptr, l == 0 ? x_ids : nullptr, x_id_rows,
-                                   decode || pairs ? ActLayout() : lay_in)))
+                                   decode || pairs ? lay_dx : lay_in)))
                 return rc;
         }
         if (split_norm) {
@@ -3270,7 +3301,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
             if ((rc = stack_swiglu(xn, H, L.wgu, L.s_gu, nullptr, 0.f, act, m->inter, N, m->inter, H, stream, lay_gu))) return rc;
         } else {
             LayerEventScope ev(m, l, QTTS_LAUNCH_GATE_UP, stream);
-            if ((rc = stack_swiglu(xa, H, L.wgu, L.s_gu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream))) return rc;
+            if ((rc = stack_swiglu(xa, H, L.wgu, L.s_gu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream, lay_dgu))) return rc;
         }
         // a prompt's K-split down_proj also normalises the finished rows for whoever reads them next: the next
         // layer's input norm, or the final norm (the returned hidden state)
@@ -3278,7 +3309,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         const bool fuse_next = split_norm && linear_rows_is_ksplit(N, H, m->inter, W.parts_bytes);
         LayerEventScope ev_down(m, l, QTTS_LAUNCH_DOWN, stream);
         ActLayout lay_down;
-        lay_down.xpacked = split_norm ? frag : 0;
+        lay_down.xpacked = split_norm ? frag : dfrag;
         lay_down.nnpks = fuse_next && !last ? pkH : 0;   // the next layer's normalised rows; the returned hidden state stays row-major
         if ((rc = stack_linear(act, m->inter, L.wdown, L.s_down, xa, H, nullptr, fuse_next ? m->eps : 0.f, xb, H, N, H, m->inter,
                                (float *)(m->ws + W.parts), W.parts_bytes, stream,

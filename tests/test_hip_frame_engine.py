@@ -131,10 +131,11 @@ def test_capture_all_then_no_capture_while_serving(tmp_path):
     assert outs[0] == outs[1]
 
 
-@pytest.mark.parametrize("max_streams", [3, 5, 24])
+@pytest.mark.parametrize("max_streams", [3, 5, 12, 24])
 def test_stream_counts_between_the_power_of_two_buckets(tmp_path, max_streams):
-    """An engine sized for 3, 5 or 24 streams (not one of the batch buckets 1, 2, 4, 8, 16, 32 ...) runs its full
-    batch, and every stream's ids equal a solo run of the same prompt."""
+    """An engine sized for 3, 5, 12 or 24 streams (not one of the batch buckets 1, 2, 4, 8, 16, 32 ...) runs its full
+    batch, and every stream's ids equal a solo run of the same prompt (12 streams: the 16-row steps hand the attention
+    and SwiGLU outputs to the next GEMM in fragment order, a solo run row-major)."""
     from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
     cfg, sd, tw, pw = golden_weights("tiny", 11)
     json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
@@ -157,11 +158,14 @@ def test_stream_counts_between_the_power_of_two_buckets(tmp_path, max_streams):
     solo.exit()
 
 
-def test_full_size_batch_invariance_and_graph_equals_eager(tmp_path):
-    """Qwen3-TTS-1.7B shapes (28 + 5 layers, the bench's random-init weights), 8 streams, 3 frames.  Two properties
+@pytest.mark.parametrize("B", [8, 12])
+def test_full_size_batch_invariance_and_graph_equals_eager(tmp_path, B):
+    """Qwen3-TTS-1.7B shapes (28 + 5 layers, the bench's random-init weights), 8 or 12 streams, 3 frames.  Two properties
     that hold at any size because every row of a step is computed independently of the others and a graph replays
     the launches it captured: (1) the frame graphs return exactly the ids of eager launches; (2) a stream run alone
-    returns exactly the ids it gets inside a batch of 8 (equal prompt lengths, so the attention split is the same)."""
+    returns exactly the ids it gets inside the batch (equal prompt lengths, so the attention split is the same).
+    With 12 streams the steps are 16 rows wide: no shared prologue lanes, activations between the kernels of a layer
+    in fragment order - other kernel forms than the solo run's, the same bits."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -171,7 +175,7 @@ def test_full_size_batch_invariance_and_graph_equals_eager(tmp_path):
     dev = torch.device("cuda")
     tw, pw = bench.make_weights(cfg, dev)
     json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
-    H, B, NF, L = cfg["talker_config"]["hidden_size"], 8, 3, 100
+    H, NF, L = cfg["talker_config"]["hidden_size"], 3, 100
     g = torch.Generator().manual_seed(77)
     prompts = [(torch.randn(L, H, generator=g) * 0.5) for _ in range(B)]
     texts = [(torch.randn(NF + 2, H, generator=g) * 0.1) for _ in range(B)]

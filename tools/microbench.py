@@ -141,8 +141,9 @@ def linear2():
 
 
 def lat():
-    """Where a small GEMM launch spends its time: weights L2-hot (flag 1), no activation loads (flag 2), both (3)."""
-    B = 8
+    """Where a small GEMM launch spends its time: weights L2-hot (flag 1), no activation loads (flag 2), both (3).
+    QTTS_LAT_ROWS: rows of the launch (8; 9-16 rows take the form without shared activation lanes)."""
+    B = int(os.environ.get("QTTS_LAT_ROWS", "8"))
     shapes = [("o pred", 1024, 2048, "res"), ("down pred", 1024, 3072, "res"), ("qkv pred", 4096, 1024, "norm"),
               ("head pred", 2048, 1024, "norm"), ("o 1.7B", 2048, 2048, "res"), ("qkv 1.7B", 4096, 2048, "norm")]
     hot = os.environ.get("QTTS_LAT_HOT") == "1"           # one weight buffer replayed: it stays in L2 / Infinity Cache
@@ -151,7 +152,7 @@ def lat():
         ws = [torch.randn(N * K, device=dev).bfloat16() * 0.02 for _ in range(1 if hot else nbuf)]
         if hot:
             ws = ws * nbuf
-        x = torch.randn(B, K, device=dev).bfloat16()
+        x = torch.randn(max(B, 16), K, device=dev).bfloat16()[:B]
         nw = torch.ones(K, device=dev).bfloat16()
         out = torch.empty(B, N, dtype=torch.bfloat16, device=dev)
         res = torch.randn(B, N, device=dev).bfloat16()
@@ -160,7 +161,7 @@ def lat():
         def run():
             for w in ws:
                 hip.linear_fused(x, w, N, K=K, norm_w=nw if kind == "norm" else None, residual=res if kind != "norm" else None, out=out)
-        for flags in (0, 2):
+        for flags in (0, 128):                              # 128: activations read as one KiB per request (timing only)
             hip.lib.qtts_debug_linear(flags)
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
