@@ -141,8 +141,10 @@ def linear2():
 
 
 def lat():
-    """Where a small GEMM launch spends its time: weights L2-hot (flag 1), no activation loads (flag 2), both (3).
-    QTTS_LAT_ROWS: rows of the launch (8; 9-16 rows take the form without shared activation lanes)."""
+    """Small decode GEMM launches, back to back in one graph, with the activations read row-major (dbg0) and as if they
+    lay in fragment order (dbg128: one contiguous KiB per request; values are wrong for row-major inputs, timing only;
+    plain prologues of 9-16 rows only - the other forms ignore the flag).  QTTS_LAT_HOT=1: one weight buffer replayed.
+    QTTS_LAT_ROWS: rows of the launch (default 8)."""
     B = int(os.environ.get("QTTS_LAT_ROWS", "8"))
     shapes = [("o pred", 1024, 2048, "res"), ("down pred", 1024, 3072, "res"), ("qkv pred", 4096, 1024, "norm"),
               ("head pred", 2048, 1024, "norm"), ("o 1.7B", 2048, 2048, "res"), ("qkv 1.7B", 4096, 2048, "norm")]
