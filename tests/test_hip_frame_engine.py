@@ -158,8 +158,8 @@ def test_stream_counts_between_the_power_of_two_buckets(tmp_path, max_streams):
     solo.exit()
 
 
-@pytest.mark.parametrize("B", [8, 12])
-def test_full_size_batch_invariance_and_graph_equals_eager(tmp_path, B):
+@pytest.mark.parametrize("B,weights", [(8, "bf16"), (12, "bf16"), (12, "fp8")])
+def test_full_size_batch_invariance_and_graph_equals_eager(tmp_path, monkeypatch, B, weights):
     """Qwen3-TTS-1.7B shapes (28 + 5 layers, the bench's random-init weights), 8 or 12 streams, 3 frames.  Two properties
     that hold at any size because every row of a step is computed independently of the others and a graph replays
     the launches it captured: (1) the frame graphs return exactly the ids of eager launches; (2) a stream run alone
@@ -171,6 +171,7 @@ def test_full_size_batch_invariance_and_graph_equals_eager(tmp_path, B):
     import bench
     from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
     from nano_qwen3tts_vllm.utils import synthetic
+    monkeypatch.setenv("QTTS_WEIGHT_DTYPE", weights)
     cfg = synthetic.make_config("1.7B")
     dev = torch.device("cuda")
     tw, pw = bench.make_weights(cfg, dev)
@@ -187,6 +188,7 @@ def test_full_size_batch_invariance_and_graph_equals_eager(tmp_path, B):
             fe.add_stream(prompts[i].to(dev), texts[i].to(dev), max_frames=NF + 1, talker_sampling=greedy(1),
                           predictor_sampling=greedy(17, 0.9))
         ids = fe.run_frames(NF).permute(1, 0, 2)[:len(which)].clone()
+        assert fe.tr.decoder.weight_dtype == weights and fe.pr.decoder.weight_dtype == weights
         fe.exit()
         return ids
 
