@@ -3246,8 +3246,8 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     // share the prologue with, as up to 8 rows), so the two activations a layer produces for a plain prologue -
     // attention output for o_proj, SwiGLU output for down_proj - are handed over in fragment order: one contiguous
     // KiB per request instead of 64 bytes from each of 16 rows.
-    // (The 2-position prompts of up to 8 fresh sequences are such a step too.)
-    const bool dfrag = decode && N > 8 && N <= 16 && m->ws_rows >= 16;
+    // (The 2-position prompts of up to 8 fresh sequences are such a step too, and so is a prompt of 9..16 tokens.)
+    const bool dfrag = N > 8 && N <= 16 && m->ws_rows >= 16;
     ActLayout lay_dx, lay_dgu;
     lay_dx.xpacked = dfrag;
     lay_dgu.opks = dfrag ? m->inter / 32 : 0;
@@ -3285,13 +3285,14 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
             if ((rc = qtts_qknorm_rope_store(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
                                              positions, slot_mapping, kc, vc, N, Hq, Hkv, stream))) return rc;
             if ((rc = paged_attention_impl(qkv, qkvw, kc, vc, block_tables, max_blocks, row_seq, context_lens,
-                                           max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws, stream, pkA))) return rc;
+                                           max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws, stream,
+                                           dfrag ? Hq * 128 / 32 : pkA))) return rc;
         }
         {
             LayerEventScope ev(m, l, QTTS_LAUNCH_O_PROJ, stream);
             if ((rc = stack_linear(attn, Hq * 128, L.wo, L.s_o, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, nullptr, 0, stream,
                                    nullptr, nullptr, 0, nullptr, l == 0 ? x_ids : nullptr, x_id_rows,
-                                   decode || pairs ? lay_dx : lay_in)))
+                                   split_norm ? lay_in : lay_dx)))
                 return rc;
         }
         if (split_norm) {
