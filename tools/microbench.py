@@ -154,10 +154,11 @@ def lat():
         ws = [torch.randn(N * K, device=dev).bfloat16() * 0.02 for _ in range(1 if hot else nbuf)]
         if hot:
             ws = ws * nbuf
-        x = torch.randn(max(B, 16), K, device=dev).bfloat16()[:B]
+        pad = int(os.environ.get("QTTS_LAT_PAD", "0"))      # extra elements per activation / residual / output row
+        x = torch.randn(max(B, 16), K + pad, device=dev).bfloat16()[:B, :K]
         nw = torch.ones(K, device=dev).bfloat16()
-        out = torch.empty(B, N, dtype=torch.bfloat16, device=dev)
-        res = torch.randn(B, N, device=dev).bfloat16()
+        out = torch.empty(B, N + pad, dtype=torch.bfloat16, device=dev)[:, :N]
+        res = torch.randn(B, N + pad, device=dev).bfloat16()[:, :N]
         line = f"{name:10s} N={N:5d} K={K:5d} {N*K*2/1e6:5.1f} MB:"
 
         def run():
