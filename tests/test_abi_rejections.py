@@ -73,6 +73,7 @@ def test_other_shape_and_range_checks():
     assert L.qtts_embedding_gather(P, P, P, 2048, 4, 2044, 3072, None) == -1                                      # H % 8
     assert L.qtts_predictor_input(P, P, P, P, 8, 2048, 0, None) == -1                                             # empty vocabulary
     assert L.qtts_frame_glue(P, P, P, P, 4, P, 2048, None, P, None, 8, 2048, 3072, 2048, None) == -1             # ldp < B
+    assert L.qtts_frame_glue(P, P, P, P, 8, P, 2044, None, P, None, 8, 2044, 3072, 2048, None) == -1 and "multiple of 8" in err()
     assert L.qtts_advance_decode(P, P, P, P, 0, None, None, None, 1024, 8, None) == -1                            # no block table columns
 
 
