@@ -224,6 +224,11 @@ static int g_share_prologue = 1;         // norm prologue shared between the lan
 static int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
 static int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention takes the MFMA kernel for prompts
 static int g_rows_tm = 0;                // row tiles per workgroup of the prompt GEMM (0 = chosen per shape)
+static int g_rows_tm1 = 1;               // narrow prompt GEMMs may take one row tile per workgroup
+extern "C" void qtts_tune_rows_tm1(int on) { g_rows_tm1 = on; }
+static int g_rows_norm = 1;              // prompt GEMMs normalise their rows themselves (0: a norm launch in front, for A/B runs)
+static int g_rows_norm_max = 1 << 30;    // most rows for which they do
+extern "C" void qtts_tune_rows_norm(int on, int max_rows) { g_rows_norm = on; g_rows_norm_max = max_rows; }
 extern "C" void qtts_tune_rows_tm(int tm) { g_rows_tm = tm; }
 extern "C" void qtts_tune_linear(int ksw, int t) { g_tune_ksw = ksw; g_tune_t = t; }
 extern "C" void qtts_tune_subtiles(int min_bytes) { g_sub_min_bytes = min_bytes; }
@@ -241,6 +246,9 @@ static constexpr int g_share_prologue = 1;         // norm prologue shared betwe
 static constexpr int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
 static constexpr int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention takes the MFMA kernel for prompts
 static constexpr int g_rows_tm = 0;                // row tiles per workgroup of the prompt GEMM (0 = chosen per shape)
+static constexpr int g_rows_tm1 = 1;               // narrow prompt GEMMs may take one row tile per workgroup
+static constexpr int g_rows_norm = 1;              // prompt GEMMs normalise their rows themselves
+static constexpr int g_rows_norm_max = 1 << 30;    // most rows for which they do
 #endif
 
 // ------------------------------------------------------------------ linear (skinny GEMM on MFMA)
@@ -267,6 +275,12 @@ struct LinArgs {
     // prompt GEMMs between the kernels of one layer: x / the SwiGLU output / the fused norm's output in fragment
     // order (act_index) instead of row-major
     int xpacked = 0, opks = 0, nnpks = 0;
+    // prompt GEMMs, plain epilogue: the residual rows / `out` in fragment order (k-steps = N / 32); ssq_out: the stored
+    // rows' sums of squares per 16 columns, [M][N / 16]
+    int rpks = 0, opks0 = 0;
+    float *ssq_out = nullptr;
+    // prompt GEMMs, prologue 3: RMSNorm(x) * nw with the rows' sums of squares taken from ssq_in [M][K / 16]
+    const float *ssq_in = nullptr;
     int dbg;      // bit0: tuning experiment (every tile reads weight tile 0); bit3: `ids` select the residual rows, not the
                   // x rows; bits 4-5: log2 of the workgroups per tile; bit 7: x in fragment order (one row tile);
                   // bits 8+: row-tile count of a prefill launch
@@ -290,6 +304,25 @@ __device__ __forceinline__ void unpack2(uint32_t w, float &a, float &b) {
 }
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
     return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+}
+
+// RMSNorm of two neighbouring elements (one dword of bf16 pairs): bf16(bf16(x * rstd) * w), the reference's rounding
+// points (P/layers/layernorm.py:17-27), on the packed fp32 multiplier and the packed fp32 -> bf16 conversion (half the
+// instructions of the element-by-element form, same bits).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2v(float2_t v) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));       // v_cvt_pk_bf16_f32: RNE
+}
+__device__ __forceinline__ float2_t unpack2v(uint32_t w) {
+    return float2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+}
+__device__ __forceinline__ uint32_t norm_pair(uint32_t xw, float rstd, float2_t w2) {
+    const float2_t v = unpack2v(xw) * float2_t{rstd, rstd};
+    return pack2v(unpack2v(pack2v(v)) * w2);
+}
+__device__ __forceinline__ uint4 norm_frag(uint4 x, float rstd, uint4 w) {
+    return make_uint4(norm_pair(x.x, rstd, unpack2v(w.x)), norm_pair(x.y, rstd, unpack2v(w.y)),
+                      norm_pair(x.z, rstd, unpack2v(w.z)), norm_pair(x.w, rstd, unpack2v(w.w)));
 }
 
 // EPI: 0 = bias/residual epilogue; 1 = SwiGLU: a tile's rows 0..7 are gate rows and rows 8..15 the up rows of the
@@ -548,17 +581,7 @@ __global__ __launch_bounds__(512) void linear2_kernel(const bf16_t *x, const uin
         for (int i = 0; i < KSW; ++i) {
             if (H8 && i % 2) continue;
             const int k = 32 * (ks0 + i + hi) + 8 * g;
-            const uint4 wv = nwv[i];
-            const uint32_t x4[4] = {xb[i].u.x, xb[i].u.y, xb[i].u.z, xb[i].u.w}, w4[4] = {wv.x, wv.y, wv.z, wv.w};
-            uint32_t o4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v0, v1, w0, w1;
-                unpack2(x4[j], v0, v1);
-                unpack2(w4[j], w0, w1);
-                o4[j] = pack2(rbf(v0 * rstd) * w0, rbf(v1 * rstd) * w1);
-            }
-            xb[i].u = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            xb[i].u = norm_frag(xb[i].u, rstd, nwv[i]);
             if (p.xnorm_out && bx == 0 && sub == 0 && xvalid)
                 *reinterpret_cast<uint4 *>(p.xnorm_out + (size_t)xm * p.ldxn + k) = xb[i].u;
             // H8: the partner lane's k-step (lanes r >= 8 end up with a copy of row r - 8: columns never stored)
@@ -706,12 +729,30 @@ struct RowsArgs {
     int xpacked;                 // x is in fragment order (act_index): whole 16-row tiles
     int opks;                    // EPI 1: > 0 = `out` in fragment order with this many k-steps (the next GEMM's K / 32)
     int xnpks;                   // K-split: > 0 = the fused norm's output in fragment order
+    int rpks, opks0;             // EPI 0: > 0 = the residual rows / `out` in fragment order with this many k-steps (N / 32)
+    float *ssq_out;              // EPI 0: non-null = sum of squares of every stored row over the 16 columns of a weight
+                                 // tile, ssq_out[row][N / 16] (what the RMSNorm of the finished rows starts from)
+    // NORM: x holds raw rows; RMSNorm(x) * nw is applied in registers, the rows' sums of squares come from the
+    // producer's partials ssq_in[row][ssq_parts] (ssq_parts = K / 16: a multiple of 8, ssq_parts / 8 a power of two <= 16)
+    const float *ssq_in; int ssq_parts;
+    const bf16_t *nw; float eps;
+    bf16_t *xnorm_out; int ldxn; // NORM: non-null = the normalised rows, row-major (written by the first column block)
 #ifdef QTTS_TUNING
     long long *trace;            // 32 timestamps per workgroup
 #endif
 };
 
-template <int KSW, int TM, int EPI, bool W8 = false>
+// Sum over the q = 1, 2, 4, 8 or 16 neighbouring lanes of a 16-lane row that hold the parts of one value; every lane ends
+// up with the same bits (each step adds the two halves symmetrically).
+__device__ __forceinline__ float lanes_sum_q(float v, int q) {
+    if (q >= 2) v += dpp_f32<0xB1>(v);
+    if (q >= 4) v += dpp_f32<0x4E>(v);
+    if (q >= 8) v += dpp_f32<0x141>(v);
+    if (q >= 16) v += dpp_f32<0x140>(v);
+    return v;
+}
+
+template <int KSW, int TM, int EPI, bool W8 = false, bool NORM = false>
 __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const uint4 *wp, int ldx, int N, int M,
                                                           int tiles_per_wg, const RowsArgs p) {
 #ifdef QTTS_TUNING
@@ -738,6 +779,29 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
     constexpr int NLD = W8 ? KSW / 2 : KSW;
     const int KSP = W8 ? p.KS >> 1 : p.KS, kp0 = W8 ? ks0 >> 1 : ks0;
 
+    // NORM: the rows arrive raw and are normalised here.  Their sums of squares were left by the producing GEMM as one
+    // partial per (row, 16 columns); thread (row, j) of the workgroup adds 8 of a row's partials, the q = parts / 8
+    // threads of a row add theirs up across lanes, the row's total goes through LDS.  The order of these additions
+    // depends on the partial count only, not on the rows of the launch.  These small requests and the norm weights go
+    // out first: a wave's requests are served in order, and everything else waits for them.
+    constexpr int NPASS = NORM ? (TM * 16 * 16 + 511) / 512 : 1;     // passes of 512 threads over TM * 16 rows x (at most) 16 threads
+    float4_t sq[NPASS][2];
+    uint4 nwv[NORM ? KSW : 1];
+    const int sq_q = NORM ? p.ssq_parts >> 3 : 1;
+    if constexpr (NORM) {
+        const int qsh = 31 - __builtin_clz(sq_q);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int idx = ps * 512 + threadIdx.x;
+            const int rl = min(idx >> qsh, TM * 16 - 1), j = idx & (sq_q - 1);
+            const int mrow = min(by * TM * 16 + rl, M - 1);
+            const float *sp = p.ssq_in + (size_t)mrow * p.ssq_parts + 8 * j;
+            sq[ps][0] = *reinterpret_cast<const float4_t *>(sp);
+            sq[ps][1] = *reinterpret_cast<const float4_t *>(sp + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < KSW; ++k) nwv[k] = *reinterpret_cast<const uint4 *>(p.nw + 32 * (ks0 + k) + 8 * g);
+    }
     // rows beyond M read row 0: their accumulator columns are never stored
     Frag xb[TM][KSW];
 #pragma unroll
@@ -764,12 +828,55 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
 #pragma unroll
         for (int k = 0; k < NLD; ++k) a[j][k].u = wptr[k * wstep0];
     }
+    if constexpr (NORM) {
+        float *rowsum = reinterpret_cast<float *>(smem4 + (size_t)2 * NW * TM * 64);
+        const int qsh = 31 - __builtin_clz(sq_q);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int idx = ps * 512 + threadIdx.x;
+            float v = sq[ps][0][0];
+            v += sq[ps][0][1]; v += sq[ps][0][2]; v += sq[ps][0][3];
+            v += sq[ps][1][0]; v += sq[ps][1][1]; v += sq[ps][1][2]; v += sq[ps][1][3];
+            v = lanes_sum_q(v, sq_q);
+            if ((idx & (sq_q - 1)) == 0 && (idx >> qsh) < TM * 16) rowsum[idx >> qsh] = v;
+        }
+        __syncthreads();
+        const float kf = (float)(p.KS * 32);
+        float rstd[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rstd[i] = 1.0f / sqrtf(rowsum[i * 16 + r] / kf + p.eps);
+#pragma unroll
+        for (int k = 0; k < KSW; ++k) {
+            const float2_t w2[4] = {unpack2v(nwv[k].x), unpack2v(nwv[k].y), unpack2v(nwv[k].z), unpack2v(nwv[k].w)};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const uint4 xv = xb[i][k].u;
+                xb[i][k].u = make_uint4(norm_pair(xv.x, rstd[i], w2[0]), norm_pair(xv.y, rstd[i], w2[1]),
+                                        norm_pair(xv.z, rstd[i], w2[2]), norm_pair(xv.w, rstd[i], w2[3]));
+                const int mi = (by * TM + i) * 16 + r;
+                if (p.xnorm_out && bx == 0 && mi < M)
+                    *reinterpret_cast<uint4 *>(p.xnorm_out + (size_t)mi * p.ldxn + 32 * (ks0 + k) + 8 * g) = xb[i][k].u;
+            }
+        }
+    }
+    // Plain epilogue: where this lane's four columns of weight tile t lie in the residual rows and in `out`, as
+    // base + t * stride.  Row-major: m * ld + 4 g, 16 columns per tile; fragment order (act_index): tile t is half a
+    // k-step, 256 elements on, and the lane's four columns sit in lane (2 (t & 1) + g / 2, r) at 4 (g & 1).
+    int res_base = 0, res_step = 16, out_base = 0, out_step = 16;
+    if (EPI == 0) {
+        const int mt = by * TM + wave, m = mt * 16 + r;
+        const int fbase = (((g >> 1) << 4) + r) * 8 + 4 * (g & 1);
+        res_base = p.rpks ? mt * p.rpks * 512 + fbase : m * p.ldr + 4 * g;
+        out_base = p.opks0 ? mt * p.opks0 * 512 + fbase : m * p.ldo + 4 * g;
+        res_step = p.rpks ? 256 : 16;
+        out_step = p.opks0 ? 256 : 16;
+    }
     auto tile_body = [&](const int cur, const int it) {
         const int t = t_begin + it;
         uint2 resw = make_uint2(0, 0);
         if (EPI == 0 && wave < TM) {
             const int m = (by * TM + wave) * 16 + r;
-            if (p.res && m < M) resw = *reinterpret_cast<const uint2 *>(p.res + (size_t)m * p.ldr + 16 * t + 4 * g);
+            if (p.res && m < M) resw = *reinterpret_cast<const uint2 *>(p.res + (size_t)(res_base + t * res_step));
         }
         // fp8 weights: the rows' scales, requested here and not in the epilogue (a late load is waited for together
         // with the weight tiles requested after it)
@@ -845,20 +952,26 @@ __global__ __launch_bounds__(512) void linear_rows_kernel(const bf16_t *x, const
             }
             return;
         }
-        if (m < M) {
-            // (no bias here: a load this late is waited for with every younger request, i.e. with the weight tiles
-            // in flight for the next bodies; GEMMs with a bias take the single-tile kernel or the K-split epilogue)
-            float v[4], rf[4];
-            unpack2(resw.x, rf[0], rf[1]);
-            unpack2(resw.y, rf[2], rf[3]);
+        // (no bias here: a load this late is waited for with every younger request, i.e. with the weight tiles
+        // in flight for the next bodies; GEMMs with a bias take the single-tile kernel or the K-split epilogue)
+        float v[4], rf[4];
+        unpack2(resw.x, rf[0], rf[1]);
+        unpack2(resw.y, rf[2], rf[3]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float q = rbf(sum[j]);
-                if (p.res) q = q + rf[j];
-                v[j] = q;
-            }
-            *reinterpret_cast<uint2 *>(p.out + (size_t)m * p.ldo + 16 * t + 4 * g) =
-                make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+        for (int j = 0; j < 4; ++j) {
+            float q = rbf(sum[j]);
+            if (p.res) q = q + rf[j];
+            v[j] = rbf(q);                                 // the value as it is stored
+        }
+        if (m < M)
+            *reinterpret_cast<uint2 *>(p.out + (size_t)(out_base + t * out_step)) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+        if (p.ssq_out) {
+            // the row's sum of squares over this tile's 16 columns: four columns per lane, then the four lanes of the row
+            float s2 = v[0] * v[0];
+            s2 += v[1] * v[1]; s2 += v[2] * v[2]; s2 += v[3] * v[3];
+            s2 += __shfl_xor(s2, 16);
+            s2 += __shfl_xor(s2, 32);
+            if (g == 0 && m < M) p.ssq_out[(size_t)m * (N >> 4) + t] = s2;
         }
     };
     // groups of four tiles as straight-line code: inside a group the compiler counts outstanding loads exactly
@@ -930,10 +1043,10 @@ __global__ __launch_bounds__(256) void linear_parts_kernel(const float *part, in
 __global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *part, int kparts, int mpad, int N,
                                                                 const bf16_t *bias, const bf16_t *res, int ldr, bf16_t *out,
                                                                 int ldo, const bf16_t *nw, float eps, bf16_t *xn, int ldxn,
-                                                                int xnpks) {
+                                                                int xnpks, int rpks, int opks0) {
+    // rpks / opks0 > 0: the residual rows / `out` in fragment order (act_index; a thread's 8 columns stay contiguous)
     __shared__ float red[4];
     const int m = blockIdx.x;
-    bf16_t *orow = out + (size_t)m * ldo;
     float ss = 0.f;
     for (int n = threadIdx.x * 8; n < N; n += 256 * 8) {
         float q[8];
@@ -944,7 +1057,7 @@ __global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *par
             for (int j = 0; j < 4; ++j) q[4 * hlf + j] = sum[j];
         }
         Frag rf, bfv, o;
-        rf.u = res ? *reinterpret_cast<const uint4 *>(res + (size_t)m * ldr + n) : make_uint4(0, 0, 0, 0);
+        rf.u = res ? *reinterpret_cast<const uint4 *>(res + act_index(m, n, ldr, rpks)) : make_uint4(0, 0, 0, 0);
         bfv.u = bias ? *reinterpret_cast<const uint4 *>(bias + n) : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -956,7 +1069,7 @@ __global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *par
             const float r = bf2f(o.h[j]);
             ss += r * r;
         }
-        *reinterpret_cast<uint4 *>(orow + n) = o.u;
+        *reinterpret_cast<uint4 *>(out + act_index(m, n, ldo, opks0)) = o.u;
     }
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
@@ -964,12 +1077,9 @@ __global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *par
     const float tot = red[0] + red[1] + red[2] + red[3];
     const float rstd = 1.0f / sqrtf(tot / (float)N + eps);
     for (int n = threadIdx.x * 8; n < N; n += 256 * 8) {
-        Frag f, wv, o;
-        f.u = *reinterpret_cast<const uint4 *>(orow + n);          // this thread's own stores
-        wv.u = *reinterpret_cast<const uint4 *>(nw + n);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.h[j] = f2bf(rbf(bf2f(f.h[j]) * rstd) * bf2f(wv.h[j]));
-        *reinterpret_cast<uint4 *>(xn + act_index(m, n, ldxn, xnpks)) = o.u;
+        const uint4 f = *reinterpret_cast<const uint4 *>(out + act_index(m, n, ldo, opks0));          // this thread's own stores
+        const uint4 wv = *reinterpret_cast<const uint4 *>(nw + n);
+        *reinterpret_cast<uint4 *>(xn + act_index(m, n, ldxn, xnpks)) = norm_frag(f, rstd, wv);
     }
 }
 
@@ -1024,17 +1134,24 @@ static void launch_linear2_inst(dim3 grid, int NW, hipStream_t s, const LinArgs 
                             a.K, a.N, a.M, a.tiles_per_wg, a.dbg, a.id_rows, a.nw, a.eps, tl);
 }
 
-template <int KSW, int TM, int EPI>
+template <int KSW, int TM, int EPI, bool NORM = false>
 static bool launch_rows_inst(dim3 grid, hipStream_t s, const LinArgs &a, int tpw, const RowsArgs &r) {
-    const size_t shmem = (size_t)2 * 8 * TM * 64 * sizeof(float4_t);
+    const size_t shmem = (size_t)2 * 8 * TM * 64 * sizeof(float4_t) + (NORM ? (size_t)TM * 16 * sizeof(float) : 0);
     if (a.wscale) {
-        if (!allow_dynamic_lds(reinterpret_cast<const void *>(&linear_rows_kernel<KSW, TM, EPI, true>), shmem)) return false;
-        hipLaunchKernelGGL((linear_rows_kernel<KSW, TM, EPI, true>), grid, dim3(512), shmem, s, a.x, a.wp, a.ldx, a.N, a.M, tpw, r);
+        if (!allow_dynamic_lds(reinterpret_cast<const void *>(&linear_rows_kernel<KSW, TM, EPI, true, NORM>), shmem)) return false;
+        hipLaunchKernelGGL((linear_rows_kernel<KSW, TM, EPI, true, NORM>), grid, dim3(512), shmem, s, a.x, a.wp, a.ldx, a.N, a.M, tpw, r);
         return true;
     }
-    if (!allow_dynamic_lds(reinterpret_cast<const void *>(&linear_rows_kernel<KSW, TM, EPI>), shmem)) return false;
-    hipLaunchKernelGGL((linear_rows_kernel<KSW, TM, EPI>), grid, dim3(512), shmem, s, a.x, a.wp, a.ldx, a.N, a.M, tpw, r);
+    if (!allow_dynamic_lds(reinterpret_cast<const void *>(&linear_rows_kernel<KSW, TM, EPI, false, NORM>), shmem)) return false;
+    hipLaunchKernelGGL((linear_rows_kernel<KSW, TM, EPI, false, NORM>), grid, dim3(512), shmem, s, a.x, a.wp, a.ldx, a.N, a.M, tpw, r);
     return true;
+}
+
+// Whether the prompt GEMM can normalise its input rows itself from the producer's sum-of-squares partials (prologue
+// 3): K = 1024 or 2048 in one part, K / 16 partials per row handled by 1..16 threads of 8.
+static bool linear_rows_norm_covers(int K) {
+    const int ksw = K / 256, parts = K / 16;
+    return K % 256 == 0 && (ksw == 4 || ksw == 8) && parts % 8 == 0 && ((parts / 8) & (parts / 8 - 1)) == 0 && parts / 8 <= 16;
 }
 
 // Bytes of fp32 scratch the K-split form of a prompt GEMM needs (0 when the GEMM runs in one part).
@@ -1071,9 +1188,11 @@ static bool linear_rows_covers(int M, int N, int K, bool silu_pairs, bool has_bi
     return true;
 }
 
-static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch, size_t scratch_bytes, hipStream_t s) {
+static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch, size_t scratch_bytes, hipStream_t s,
+                               bool norm3 = false) {
     const int KS = a.K / 32;
     if (KS % 8 != 0) return false;
+    if (norm3 && (!linear_rows_norm_covers(a.K) || !a.ssq_in || !a.nw)) return false;
     int ksw = KS / 8, kparts = 1;
     if (ksw > 12) {                                       // long K: parts of 8 k-steps per wave
         if (ksw % 8 != 0 || silu_pairs) return false;
@@ -1084,6 +1203,7 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     if (ksw != 4 && ksw != 8 && ksw != 12) return false;
     if (ksw == 12 && silu_pairs) return false;
     if (a.bias && kparts == 1) return false;              // the single-pass epilogue carries no bias
+    if (kparts > 1 && !a.next_nw && (a.rpks || a.opks0)) return false;   // (the plain K-part finish is row-major only)
     const int mtiles = (a.M + 15) / 16;
     const int ntiles = a.N / 16;
     // Row tiles per workgroup (TM).  More row tiles per workgroup mean fewer passes over the weights (fewer, longer
@@ -1107,19 +1227,26 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
         return rounds * (4 * tm + (a.wscale ? tpw_ : 2 * tpw_));
     };
     int TM = 2;
-    if (ksw != 12) {
-        const int cands[] = {4, 3, 2};
+    {
+        // (one row tile per workgroup: narrow outputs only - up to 128 weight tiles, plain epilogue, one K part - where a
+        // workgroup streams a single weight tile and the rows it has to pull in first are most of its bytes)
+        const int cands[] = {4, 3, 2, 1};
         int best = 1 << 30;
         for (int tm : cands) {
             if (tm == 3 && (ksw != 8 || kparts > 1)) continue;   // three row tiles: built for K = 2048 in one part
-            if (tm > 2 && mtiles <= 2) continue;
+            if (tm > 2 && (mtiles <= 2 || ksw == 12)) continue;
+            if (norm3 && tm > 2 && ksw == 8) continue;           // rows normalised in registers: two row tiles at K = 2048
+            if (tm == 1 && (ntiles > 128 || silu_pairs || kparts > 1 || mtiles > 4 || g_rows_tm1 == 0)) continue;
             const int c = plan(tm, nullptr);
             if (c < best) { best = c; TM = tm; }
         }
     }
-    if (g_rows_tm == 2 || (g_rows_tm == 4 && ksw != 12 && mtiles > 2) || (g_rows_tm == 3 && ksw == 8 && kparts == 1 && mtiles > 2)) TM = g_rows_tm;
+    if (!norm3 && (g_rows_tm == 2 || (g_rows_tm == 4 && ksw != 12 && mtiles > 2) || (g_rows_tm == 3 && ksw == 8 && kparts == 1 && mtiles > 2))) TM = g_rows_tm;
     RowsArgs r;
     r.bias = a.bias; r.res = a.res; r.ldr = a.ldr; r.out = a.out; r.ldo = a.ldo;
+    r.rpks = a.rpks; r.opks0 = a.opks0; r.ssq_out = kparts == 1 && !silu_pairs ? a.ssq_out : nullptr;
+    r.ssq_in = norm3 ? a.ssq_in : nullptr; r.ssq_parts = a.K / 16; r.nw = a.nw; r.eps = a.eps;
+    r.xnorm_out = norm3 ? a.xnorm_out : nullptr; r.ldxn = a.ldxn;
     r.part = scratch; r.mpad = a.M; r.rgroups = (mtiles + TM - 1) / TM; r.KS = KS;
 #ifdef QTTS_TUNING
     r.trace = g_trace;
@@ -1136,7 +1263,15 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
     const int epi = kparts > 1 ? 2 : (silu_pairs ? 1 : 0);
     bool ok = true;
 #define QR(KSW_, TM_, EPI_) ok = launch_rows_inst<KSW_, TM_, EPI_>(grid, s, a, tpw, r)
-    if (ksw == 12) QR(12, 2, 0);
+#define QRN(KSW_, TM_, EPI_) ok = launch_rows_inst<KSW_, TM_, EPI_, true>(grid, s, a, tpw, r)
+    if (norm3) {
+        if (TM == 1) { if (ksw == 8) QRN(8, 1, 0); else QRN(4, 1, 0); }
+        else if (ksw == 8) { if (epi == 0) QRN(8, 2, 0); else QRN(8, 2, 1); }
+        else if (TM == 2) { if (epi == 0) QRN(4, 2, 0); else QRN(4, 2, 1); }
+        else { if (epi == 0) QRN(4, 4, 0); else QRN(4, 4, 1); }
+    } else
+    if (TM == 1) { if (ksw == 12) QR(12, 1, 0); else if (ksw == 8) QR(8, 1, 0); else QR(4, 1, 0); }
+    else if (ksw == 12) QR(12, 2, 0);
     else if (ksw == 8) {
         if (TM == 2) { if (epi == 0) QR(8, 2, 0); else if (epi == 1) QR(8, 2, 1); else QR(8, 2, 2); }
         else if (TM == 3) { if (epi == 0) QR(8, 3, 0); else QR(8, 3, 1); }
@@ -1146,12 +1281,13 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
         else { if (epi == 0) QR(4, 4, 0); else QR(4, 4, 1); }
     }
 #undef QR
+#undef QRN
     if (!ok) return false;                               // (the caller's single-tile path still works)
     if (kparts > 1) {
         const long quads = (long)a.M * (a.N / 4);
         if (a.next_nw)
             hipLaunchKernelGGL(linear_parts_norm_kernel, dim3(a.M), dim3(256), 0, s, scratch, kparts, a.M, a.N, a.bias, a.res,
-                               a.ldr, a.out, a.ldo, a.next_nw, a.eps, a.next_xn, a.ldnn, a.nnpks);
+                               a.ldr, a.out, a.ldo, a.next_nw, a.eps, a.next_xn, a.ldnn, a.nnpks, a.rpks, a.opks0);
         else
             hipLaunchKernelGGL(linear_parts_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, scratch, kparts, a.M,
                                a.M, a.N, a.bias, a.res, a.ldr, a.out, a.ldo);
@@ -1169,15 +1305,18 @@ static int launch_linear2(LinArgs a, int pro, hipStream_t s, bool silu_pairs = f
     QCHECK(!a.res || a.ldr >= a.N, "linear: residual row stride %d < N", a.ldr);
     QCHECK(!silu_pairs || (!a.bias && !a.res && pro != 2), "linear: bad SwiGLU arguments");
     QCHECK(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.wp & 15) == 0 && ((uintptr_t)a.out & 7) == 0, "linear: misaligned pointer");
-    QCHECK(pro != 1 || a.nw, "linear: norm prologue without weight");
+    QCHECK((pro != 1 && pro != 3) || a.nw, "linear: norm prologue without weight");
     QCHECK(!a.xnorm_out || (a.ldxn % 8 == 0 && a.ldxn >= a.K), "linear: bad xnorm_out stride");
     // from two row tiles on (two row tiles per workgroup in the prompt kernel against single-tile workgroups: frames at
     // 20 / 24 / 32 streams 4.41 / 4.42 / 4.52 -> 4.13 / 4.20 / 4.31 ms, a 17..32-token prompt 2.07 -> 1.75 ms)
     QCHECK(!a.res_ids || (a.M <= 16 && a.res && a.res_id_rows > 0 && !a.ids && !a.bias), "linear: gathered residual rows need M <= 16, a residual table and plain x rows");
-    if (a.M > g_rows_min && pro == 0 && !a.ids && !(g_dbg_linear & 2) && launch_linear_rows(a, silu_pairs, scratch, scratch_bytes, s)) {
+    if (a.M > g_rows_min && (pro == 0 || pro == 3) && !a.ids && !(g_dbg_linear & 2) &&
+        launch_linear_rows(a, silu_pairs, scratch, scratch_bytes, s, pro == 3)) {
         QLAUNCH();
         return QTTS_OK;
     }
+    if (pro == 3 || a.rpks || a.opks0 || a.ssq_out)
+        QFAIL(QTTS_ESTATE, "linear: rows normalised from partial sums / fragment-order residual rows are forms of the prompt GEMM, which does not take M=%d N=%d K=%d", a.M, a.N, a.K);
     // One row tile of 9..16 rows (a decode step; up to 8 rows the lanes share the prologue instead): x of a plain
     // prologue and the SwiGLU output may be in fragment order as well
     const bool tile_frag = a.M > 8 && a.M <= 16 && !a.nnpks && (!a.xpacked || (pro == 0 && !a.ids)) && (!a.opks || silu_pairs);
@@ -1337,14 +1476,13 @@ extern "C" int qtts_linear_swiglu_fp8(const void *x, int ldx, const void *w_gate
 
 // ------------------------------------------------------------------ rmsnorm (stand-alone)
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t *__restrict__ x, int ldx, const bf16_t *__restrict__ w,
-                                                      float eps, bf16_t *__restrict__ y, int ldy, int H, int ypks) {
+                                                      float eps, bf16_t *__restrict__ y, int ldy, int H, int ypks, int xpks) {
     __shared__ float red[4];
     const int row = blockIdx.x;
-    const bf16_t *xr = x + (size_t)row * ldx;
     float ss = 0.f;
     for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
         Frag f;
-        f.u = *reinterpret_cast<const uint4 *>(xr + i);
+        f.u = *reinterpret_cast<const uint4 *>(x + act_index(row, i, ldx, xpks));
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v = bf2f(f.h[j]);
@@ -1357,24 +1495,21 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t *__restrict__
     const float tot = red[0] + red[1] + red[2] + red[3];
     const float rstd = 1.0f / sqrtf(tot / (float)H + eps);
     for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
-        Frag f, wv, o;
-        f.u = *reinterpret_cast<const uint4 *>(xr + i);
-        wv.u = *reinterpret_cast<const uint4 *>(w + i);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.h[j] = f2bf(rbf(bf2f(f.h[j]) * rstd) * bf2f(wv.h[j]));
-        *reinterpret_cast<uint4 *>(y + act_index(row, i, ldy, ypks)) = o.u;
+        const uint4 f = *reinterpret_cast<const uint4 *>(x + act_index(row, i, ldx, xpks));
+        const uint4 wv = *reinterpret_cast<const uint4 *>(w + i);
+        *reinterpret_cast<uint4 *>(y + act_index(row, i, ldy, ypks)) = norm_frag(f, rstd, wv);
     }
 }
 
-// ypks > 0: y in fragment order (act_index) for a prompt GEMM that reads it so
+// ypks > 0: y in fragment order (act_index) for a prompt GEMM that reads it so; xpks > 0: x in fragment order
 static int rmsnorm_impl(const void *x, int ldx, const void *w, float eps, void *y, int ldy, int M, int H, int ypks,
-                        qtts_stream_t stream) {
+                        qtts_stream_t stream, int xpks = 0) {
     QCHECK(x && w && y, "rmsnorm: null pointer");
     QCHECK(M > 0 && H > 0 && H % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= H && ldy >= H,
            "rmsnorm: bad shape M=%d H=%d ldx=%d ldy=%d", M, H, ldx, ldy);
-    QCHECK(ypks == 0 || ypks * 32 == H, "rmsnorm: fragment-order output needs H = 32 * k-steps");
+    QCHECK((ypks == 0 || ypks * 32 == H) && (xpks == 0 || xpks * 32 == H), "rmsnorm: fragment-order rows need H = 32 * k-steps");
     hipLaunchKernelGGL(rmsnorm_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, ldx,
-                       (const bf16_t *)w, eps, (bf16_t *)y, ldy, H, ypks);
+                       (const bf16_t *)w, eps, (bf16_t *)y, ldy, H, ypks, xpks);
     QLAUNCH();
     return QTTS_OK;
 }
@@ -2253,7 +2388,7 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
     a.part_o = (float *)partials; a.part_ml = a.part_o ? a.part_o + (size_t)B * Hq * ns * 128 : nullptr; a.nsplit = ns;
     a.counters = counters;
     a.row_ids = row_ids; a.id_rows = id_rows;
-    QCHECK(opks == 0 || (B <= 16 && opks * 32 == Hq * 128), "attention_decode_fused: fragment-order output is one 16-row tile of Hq*128 columns");
+    QCHECK(opks == 0 || opks * 32 == Hq * 128, "attention_decode_fused: fragment-order output rows have Hq*128 columns (whole 16-row tiles)");
     a.opks = opks;
     dim3 grid(B, Hkv, ns);
     if (uniform) {
@@ -2977,7 +3112,12 @@ struct LayerW {
 
 // The decoder stack's GEMMs with bf16 or fp8 weights (wscale != null).
 // How a prompt GEMM's activations are laid out (all zero: row-major everywhere)
-struct ActLayout { int xpacked = 0, opks = 0, nnpks = 0; };
+struct ActLayout {
+    int xpacked = 0, opks = 0, nnpks = 0;
+    int rpks = 0, opks0 = 0;            // plain epilogue: residual rows / output in fragment order
+    float *ssq_out = nullptr;           // plain epilogue: the stored rows' sums of squares per 16 columns
+    const float *ssq_in = nullptr;      // with a norm weight: the rows are normalised from these partials (prologue 3)
+};
 
 static int stack_linear(const void *x, int ldx, const void *w, const float *wscale, const void *residual, int ldr,
                         const void *norm_w, float eps, void *out, int ldo, int M, int N, int K, float *scratch,
@@ -2991,7 +3131,8 @@ static int stack_linear(const void *x, int ldx, const void *w, const float *wsca
     a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = x_ids; a.id_rows = x_ids ? id_rows : 0; a.wp = (const uint4 *)w; a.wscale = wscale;
     a.bias = nullptr; a.res = (const bf16_t *)residual; a.ldr = ldr; a.nw = (const bf16_t *)norm_w; a.eps = eps;
     a.xnorm_out = nullptr; a.ldxn = 0; a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.tiles_per_wg = 1;
-    return launch_linear2(a, norm_w ? 1 : 0, (hipStream_t)stream, false, scratch, scratch_bytes);
+    a.rpks = lay.rpks; a.opks0 = lay.opks0; a.ssq_out = lay.ssq_out; a.ssq_in = lay.ssq_in;
+    return launch_linear2(a, norm_w ? (lay.ssq_in ? 3 : 1) : 0, (hipStream_t)stream, false, scratch, scratch_bytes);
 }
 
 static int stack_swiglu(const void *x, int ldx, const void *wgu, const float *wscale, const void *norm_w, float eps,
@@ -3001,7 +3142,8 @@ static int stack_swiglu(const void *x, int ldx, const void *wgu, const float *ws
     a.x = (const bf16_t *)x; a.ldx = ldx; a.ids = nullptr; a.id_rows = 0; a.wp = (const uint4 *)wgu; a.wscale = wscale;
     a.bias = nullptr; a.res = nullptr; a.ldr = 0; a.nw = (const bf16_t *)norm_w; a.eps = eps; a.xnorm_out = nullptr;
     a.ldxn = 0; a.out = (bf16_t *)out; a.ldo = ldo; a.M = M; a.N = 2 * I; a.K = K; a.tiles_per_wg = 1;
-    return launch_linear2(a, norm_w ? 1 : 0, (hipStream_t)stream, true);
+    a.ssq_in = lay.ssq_in;
+    return launch_linear2(a, norm_w ? (lay.ssq_in ? 3 : 1) : 0, (hipStream_t)stream, true);
 }
 
 struct qtts_model {
@@ -3131,7 +3273,7 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 #define QTTS_MAX_DECODE_ROWS 512   // sequences per decode step: the reference's max_num_seqs (P/config.py:45)
 
 struct WsLayout {
-    size_t qkv, attn, act, xa, xb, xn, parts, parts_bytes, att_ws, att_cnt, total;
+    size_t qkv, attn, act, xa, xb, xn, ssq, parts, parts_bytes, att_ws, att_cnt, total;
 };
 
 static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
@@ -3142,9 +3284,10 @@ static WsLayout ws_layout(const qtts_model *m, int rows, int max_context) {
     const size_t rows16 = ((size_t)rows + 15) & ~(size_t)15;      // fragment-order buffers hold whole 16-row tiles
     L.attn = off; off += align256(rows16 * m->n_heads * 128 * 2);
     L.act = off; off += align256(rows16 * m->inter * 2);
-    L.xa = off; off += align256((size_t)rows * m->hidden * 2);
-    L.xb = off; off += align256((size_t)rows * m->hidden * 2);
+    L.xa = off; off += align256(rows16 * m->hidden * 2);              // (residual stream: fragment order inside a prompt's layers)
+    L.xb = off; off += align256(rows16 * m->hidden * 2);
     L.xn = off; off += align256(rows16 * m->hidden * 2);              // normalised rows of a prompt (prefill GEMMs)
+    L.ssq = off; off += align256(rows16 * (m->hidden / 16) * sizeof(float));   // residual rows' sums of squares per 16 columns
     L.parts_bytes = linear_rows_scratch_bytes(rows, m->hidden, m->inter);   // K parts of a prompt's down projection
     L.parts = off; off += align256(L.parts_bytes);
     // prefill and decode attention share the partials region; the decode kernel's arrival counters follow it.
@@ -3237,9 +3380,16 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     const int pkH = frag ? H / 32 : 0, pkA = frag ? Hq * 128 / 32 : 0, pkI = frag ? m->inter / 32 : 0;
     ActLayout lay_in;                                  // a GEMM reading fragment-order rows
     lay_in.xpacked = frag;
+    // Such a prompt also keeps its residual stream in fragment order from the first o_proj on, and the GEMMs that
+    // finish residual rows (o_proj, a single-pass down_proj) leave every row's sum of squares per 16 columns behind:
+    // the GEMM that consumes the rows normalised (gate/up, the next layer's qkv, the head) then computes the row
+    // scale from those partials and normalises in registers, and the RMSNorm launch between the two is gone.
+    const bool n3 = frag && g_rows_norm && N <= g_rows_norm_max && linear_rows_norm_covers(H);
+    float *ssq = (float *)(m->ws + W.ssq);
     const float scale = 1.0f / sqrtf((float)m->head_dim);
     const size_t layer_kv = (size_t)m->num_blocks * QTTS_KV_BLOCK * Hkv * 128 * 2;   // bytes per layer per K or V
     const bf16_t *cur = (const bf16_t *)x;
+    bool cur_frag = false, cur_ssq = false;            // `cur` in fragment order / its sums of squares are in `ssq`
     int rc;
     const bool decode = row_seq == nullptr;           // one row per sequence: fused norm/RoPE/store/attention
     // Decode steps of 9..16 rows: every lane of a GEMM's activation requests carries a row of its own (no lanes to
@@ -3257,11 +3407,20 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         char *kc = m->kv + (size_t)l * layer_kv;
         char *vc = m->kv + ((size_t)m->n_layers + l) * layer_kv;
         if (split_norm) {
-            if (!xn_ready && (rc = rmsnorm_impl(cur, H, L.in_norm, m->eps, xn, H, N, H, pkH, stream))) return rc;
+            if (!xn_ready && cur_ssq) {
+                // the rows are normalised inside the GEMM
+                ActLayout lay = lay_in;
+                lay.ssq_in = ssq;
+                if ((rc = stack_linear(cur, H, L.wqkv, L.s_qkv, nullptr, 0, L.in_norm, m->eps, qkv, qkvw, N, qkvw, H, nullptr, 0, stream,
+                                       nullptr, nullptr, 0, nullptr, nullptr, 0, lay)))
+                    return rc;
+            } else {
+                if (!xn_ready && (rc = rmsnorm_impl(cur, H, L.in_norm, m->eps, xn, H, N, H, pkH, stream, cur_frag ? pkH : 0))) return rc;
+                if ((rc = stack_linear(xn, H, L.wqkv, L.s_qkv, nullptr, 0, nullptr, 0.f, qkv, qkvw, N, qkvw, H, nullptr, 0, stream,
+                                       nullptr, nullptr, 0, nullptr, nullptr, 0, lay_in)))
+                    return rc;
+            }
             xn_ready = false;
-            if ((rc = stack_linear(xn, H, L.wqkv, L.s_qkv, nullptr, 0, nullptr, 0.f, qkv, qkvw, N, qkvw, H, nullptr, 0, stream,
-                                   nullptr, nullptr, 0, nullptr, nullptr, 0, lay_in)))
-                return rc;
         } else if (l == 0 && qkv0_rows) {
             // layer 0's normalised, projected rows come from the table
         } else {
@@ -3280,7 +3439,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
                                                   m->max_pos, positions, slot_mapping, kc, vc, block_tables, max_blocks,
                                                   context_lens, max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws,
                                                   (int *)(m->ws + W.att_cnt), (hipStream_t)stream,
-                                                  tab0 ? x_ids : nullptr, x_id_rows, dfrag ? Hq * 128 / 32 : 0))) return rc;
+                                                  tab0 ? x_ids : nullptr, x_id_rows, dfrag ? Hq * 128 / 32 : pkA))) return rc;
         } else {
             if ((rc = qtts_qknorm_rope_store(qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT, m->max_pos,
                                              positions, slot_mapping, kc, vc, N, Hq, Hkv, stream))) return rc;
@@ -3290,16 +3449,26 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         }
         {
             LayerEventScope ev(m, l, QTTS_LAUNCH_O_PROJ, stream);
+            ActLayout lay = split_norm ? lay_in : lay_dx;
+            if (n3) {
+                lay.rpks = cur_frag ? pkH : 0;
+                lay.opks0 = pkH;
+                lay.ssq_out = ssq;
+            }
             if ((rc = stack_linear(attn, Hq * 128, L.wo, L.s_o, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, nullptr, 0, stream,
-                                   nullptr, nullptr, 0, nullptr, l == 0 ? x_ids : nullptr, x_id_rows,
-                                   split_norm ? lay_in : lay_dx)))
+                                   nullptr, nullptr, 0, nullptr, l == 0 ? x_ids : nullptr, x_id_rows, lay)))
                 return rc;
         }
         if (split_norm) {
             ActLayout lay_gu = lay_in;
             lay_gu.opks = pkI;
-            if ((rc = rmsnorm_impl(xa, H, L.post_norm, m->eps, xn, H, N, H, pkH, stream))) return rc;
-            if ((rc = stack_swiglu(xn, H, L.wgu, L.s_gu, nullptr, 0.f, act, m->inter, N, m->inter, H, stream, lay_gu))) return rc;
+            if (n3) {
+                lay_gu.ssq_in = ssq;
+                if ((rc = stack_swiglu(xa, H, L.wgu, L.s_gu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream, lay_gu))) return rc;
+            } else {
+                if ((rc = rmsnorm_impl(xa, H, L.post_norm, m->eps, xn, H, N, H, pkH, stream))) return rc;
+                if ((rc = stack_swiglu(xn, H, L.wgu, L.s_gu, nullptr, 0.f, act, m->inter, N, m->inter, H, stream, lay_gu))) return rc;
+            }
         } else {
             LayerEventScope ev(m, l, QTTS_LAUNCH_GATE_UP, stream);
             if ((rc = stack_swiglu(xa, H, L.wgu, L.s_gu, L.post_norm, m->eps, act, m->inter, N, m->inter, H, stream, lay_dgu))) return rc;
@@ -3312,6 +3481,10 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         ActLayout lay_down;
         lay_down.xpacked = split_norm ? frag : dfrag;
         lay_down.nnpks = fuse_next && !last ? pkH : 0;   // the next layer's normalised rows; the returned hidden state stays row-major
+        if (n3) {
+            lay_down.rpks = lay_down.opks0 = pkH;
+            lay_down.ssq_out = fuse_next ? nullptr : ssq;
+        }
         if ((rc = stack_linear(act, m->inter, L.wdown, L.s_down, xa, H, nullptr, fuse_next ? m->eps : 0.f, xb, H, N, H, m->inter,
                                (float *)(m->ws + W.parts), W.parts_bytes, stream,
                                fuse_next ? (last ? m->final_norm : m->layers[l + 1].in_norm) : nullptr,
@@ -3320,10 +3493,21 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         // Fixed roles: xa = post-attention residual stream, xb = layer output.  The next layer reads xb
         // (qkv GEMM, o_proj residual) before its down_proj overwrites it, all stream-ordered.
         cur = xb;
+        cur_frag = n3;
+        cur_ssq = n3 && !fuse_next;
     }
     if (head_w) {
         if (split_norm) {
-            if (!final_ready && (rc = qtts_rmsnorm(cur, H, m->final_norm, m->eps, hidden_out, H, N, H, stream))) return rc;
+            if (!final_ready && cur_ssq && vocab % 16 == 0) {
+                // the final norm inside the head GEMM; its first column block writes the normalised rows (the hidden state)
+                LinArgs a;
+                a.xpacked = 1; a.ssq_in = ssq;
+                a.x = cur; a.ldx = H; a.ids = nullptr; a.id_rows = 0; a.wp = (const uint4 *)head_w; a.bias = nullptr; a.res = nullptr;
+                a.ldr = 0; a.nw = (const bf16_t *)m->final_norm; a.eps = m->eps; a.xnorm_out = (bf16_t *)hidden_out; a.ldxn = H;
+                a.out = (bf16_t *)logits_out; a.ldo = vocab; a.M = N; a.N = vocab; a.K = H; a.tiles_per_wg = 1;
+                return launch_linear2(a, 3, (hipStream_t)stream);
+            }
+            if (!final_ready && (rc = rmsnorm_impl(cur, H, m->final_norm, m->eps, hidden_out, H, N, H, 0, stream, cur_frag ? pkH : 0))) return rc;
             return qtts_linear_fused(hidden_out, H, nullptr, 0, head_w, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, 0,
                                      logits_out, vocab, N, vocab, H, stream);
         }
@@ -3335,7 +3519,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
                                     logits_out, vocab, N, vocab, H, stream))) return rc;
         return QTTS_OK;
     }
-    if (!final_ready && (rc = qtts_rmsnorm(cur, H, m->final_norm, m->eps, hidden_out, H, N, H, stream))) return rc;
+    if (!final_ready && (rc = rmsnorm_impl(cur, H, m->final_norm, m->eps, hidden_out, H, N, H, 0, stream, cur_frag ? pkH : 0))) return rc;
     return QTTS_OK;
 }
 
@@ -3444,6 +3628,21 @@ extern "C" int qtts_debug_grid_barrier(int *mem, int iters, int nwg, int threads
     hipLaunchKernelGGL(grid_barrier_probe_kernel, dim3(nwg), dim3(threads), 0, s, mem, iters, mode, gsize, sleep);
     QLAUNCH();
     return QTTS_OK;
+}
+
+// A prompt GEMM in any of its forms by itself (timing experiments): x row-major or in fragment order, rows normalised
+// from ssq_in (with norm_w) or taken as they are, plain epilogue with the residual rows / the output in fragment order
+// and the sums of squares left in ssq_out, or the SwiGLU epilogue.
+extern "C" int qtts_debug_linear_rows(const void *x, int ldx, int xpacked, const float *ssq_in, const void *norm_w, float eps,
+                                      const void *w_packed, const void *residual, int ldr, int rpks, void *out, int ldo,
+                                      int opks0, float *ssq_out, int M, int N, int K, int swiglu, qtts_stream_t stream) {
+    LinArgs a;
+    a.x = (const bf16_t *)x; a.ldx = ldx; a.xpacked = xpacked; a.ids = nullptr; a.id_rows = 0; a.wp = (const uint4 *)w_packed;
+    a.bias = nullptr; a.res = (const bf16_t *)residual; a.ldr = ldr; a.rpks = rpks; a.nw = (const bf16_t *)norm_w; a.eps = eps;
+    a.xnorm_out = nullptr; a.ldxn = 0; a.out = (bf16_t *)out; a.ldo = ldo; a.opks0 = opks0; a.ssq_out = ssq_out; a.ssq_in = ssq_in;
+    a.M = M; a.N = N; a.K = K; a.tiles_per_wg = 1;
+    if (swiglu) a.opks = opks0, a.opks0 = 0;
+    return launch_linear2(a, norm_w ? (ssq_in ? 3 : 1) : 0, (hipStream_t)stream, swiglu != 0);
 }
 
 #include "qtts_resident.inc"

@@ -282,7 +282,9 @@ class Qwen3TTSInterface:
             admitted.append((batch, results, bool(fe.streams)))
 
         def settle():
-            retry = []
+            """Books what `admit` did (on this coroutine).  Returns the streams whose consumer went away during their
+            prefill: the caller hands them to the worker thread, the only one that talks to the engine."""
+            retry, orphans = [], []
             for batch, results, busy in admitted:
                 for req, r in zip(batch, results):
                     rid = req[0]
@@ -290,7 +292,7 @@ class Qwen3TTSInterface:
                         if rid in self._request_queues:
                             budget[rid] = req[3]
                         else:                                             # its consumer went away during the prefill
-                            fe.remove_stream(rid)
+                            orphans.append(rid)
                         continue
                     if isinstance(r, NoCapacity) and busy:               # blocks come back when a running stream ends
                         retry.append(req)
@@ -302,14 +304,23 @@ class Qwen3TTSInterface:
             admitted.clear()
             with self._fused_lock:
                 self._fused_pending[:0] = [r for r in retry if r[0] in self._request_queues]
+            return orphans
+
+        def drop(rids):
+            """Hands streams back to the engine (worker thread: remove_stream may wait for a prefill that is still
+            writing the stream's KV blocks, and the engine is only ever touched from that thread)."""
+            for rid in rids:
+                fe.remove_stream(rid)
 
         while True:
-            for rid in self._fused_cancelled:
-                fe.remove_stream(rid)
+            gone = list(self._fused_cancelled)
+            del self._fused_cancelled[:len(gone)]
+            for rid in gone:
                 budget.pop(rid, None)
-            self._fused_cancelled.clear()
             await off_loop(admit)
-            settle()
+            gone += settle()
+            if gone:
+                await off_loop(drop, gone)
             if not fe.streams:
                 self._fused_wake.clear()
                 if not self._fused_pending:
@@ -317,18 +328,24 @@ class Qwen3TTSInterface:
                 continue
             active = list(fe.streams)
             res = await (off_loop(fe.step, poll=admit) if in_flight else off_loop(fe.step))
-            settle()                      # requests admitted while the frame was in flight: budgets before frames
+            gone = settle()               # requests admitted while the frame was in flight: budgets before frames
             for rid in active + [r for r in res if r not in active]:
                 q = self._request_queues.get(rid)
                 frame = res.get(rid)
                 if frame is not None and q is not None:
                     q.put_nowait(frame)
                     budget[rid] -= 1
-                if frame is None or budget.get(rid, 0) <= 0:
-                    fe.remove_stream(rid)
+                # A stream has ended when the engine has dropped it (codec EOS, its frame budget) or its budget here is
+                # used up - not when a frame brought nothing for it: a stream whose prefill still runs beside the
+                # frames (or waits behind another group's) is in `fe.streams` but takes no part in the frame yet.
+                if rid not in fe.streams or budget.get(rid, 0) <= 0:
+                    if rid in fe.streams:
+                        gone.append(rid)
                     budget.pop(rid, None)
                     if q is not None:
                         q.put_nowait(None)
+            if gone:
+                await off_loop(drop, gone)
 
     async def _generate_async_fused(self, inputs_embeds, trailing_text_hiddens, tts_pad_embed, request_id):
         fe = self._frame_engine

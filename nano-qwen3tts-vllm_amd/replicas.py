@@ -28,13 +28,20 @@ import multiprocessing as mp
 import os
 import queue
 import threading
+import time
 import traceback
 import uuid
 
 import numpy as np
 
 _CMD_ADD, _CMD_CANCEL, _CMD_SHUTDOWN = "add", "cancel", "shutdown"
-_END = None                      # a stream's last message: (rid, None, reason)
+_END = None                      # a stream's last item in its sink: (None, reason)
+# What a replica sends: ONE message per frame for all its streams,
+#     ("frames", replica index, [request ids], int32 array [n, 16] of their codes, [(request id, reason) of streams that ended])
+# (the codes of a frame as one array: a message per stream and frame is 8 x 8 x 390 = 25 k pickled tuples a second
+# through the parent's one result thread at 8 replicas of 8 streams, and 200 k at 64 streams each), and
+#     ("__replica__", index, "ready" | "failed" | "stopped", info)
+_MSG_FRAMES = "frames"
 
 
 def frame_engine_factory(model_dir: str, max_streams: int = 8, capture: bool = True, **kw):
@@ -131,7 +138,7 @@ def replica_main(index: int, device_index: int | None, factory: str, factory_kwa
             if type(r).__name__ == "NoCapacity" and engine.streams:
                 still.append(cmd)                          # a row / KV blocks come back when a running stream ends
             else:
-                res_q.put((cmd[1], _END, f"rejected: {r}"))
+                res_q.put((_MSG_FRAMES, index, [], None, [(cmd[1], f"rejected: {r}")]))
         waiting[:] = still + later
 
     def poll():
@@ -149,17 +156,37 @@ def replica_main(index: int, device_index: int | None, factory: str, factory_kwa
         except Exception:
             err = traceback.format_exc()
             for rid in active:
-                res_q.put((rid, _END, "engine error: " + err))
                 engine.remove_stream(rid)
+            res_q.put((_MSG_FRAMES, index, [], None, [(rid, "engine error: " + err) for rid in active]))
             continue
-        for rid in active + [r for r in frames if r not in active]:
-            if rid in frames:
-                res_q.put((rid, list(frames[rid]), None))
-            if rid not in engine.streams:              # codec EOS or the stream's frame budget (or cancelled meanwhile)
-                res_q.put((rid, _END, "finished"))
+        rids = [rid for rid in active + [r for r in frames if r not in active] if rid in frames]
+        # codec EOS or the stream's frame budget (or cancelled meanwhile): the engine has dropped the stream
+        ended = [(rid, "finished") for rid in active + [r for r in frames if r not in active] if rid not in engine.streams]
+        if rids or ended:
+            codes = np.asarray([frames[rid] for rid in rids], dtype=np.int32).reshape(len(rids), -1) if rids else None
+            res_q.put((_MSG_FRAMES, index, rids, codes, ended))
     if hasattr(engine, "exit"):
         engine.exit()
     res_q.put(("__replica__", index, "stopped", None))
+
+
+class _AsyncSink:
+    """Where an async consumer's frames go: an asyncio.Queue of the consumer's event loop, filled from the result
+    thread with call_soon_threadsafe (no executor thread parked per stream)."""
+
+    def __init__(self, loop):
+        self.loop, self.q = loop, asyncio.Queue()
+
+    def put(self, item):
+        try:
+            self.loop.call_soon_threadsafe(self.q.put_nowait, item)
+        except RuntimeError:                               # the consumer's loop has been closed
+            pass
+
+
+def _put_all(batch):
+    for q, item in batch:
+        q.put_nowait(item)
 
 
 class ReplicaPool:
@@ -189,6 +216,8 @@ class ReplicaPool:
         self._dead: set[int] = set()                       # replicas whose process has gone away
         self._closed = False
         self.placements: list[tuple[str, int]] = []        # (request id, replica) in admission order
+        self.frame_messages = 0                            # frame messages read from the replicas so far
+        self.router_cpu_seconds = 0.0                      # CPU time the result thread has used
         for p in self._procs:
             p.start()
         ready = 0
@@ -228,7 +257,7 @@ class ReplicaPool:
             self._cmd_qs[i].put(msg)
 
     def submit(self, prompt_embeds, text_adds, max_frames: int, talker_sampling=None, predictor_sampling=None,
-               request_id: str | None = None) -> str:
+               request_id: str | None = None, _sink=None) -> str:
         """Queue a stream; its frames arrive through `frames(request_id)`.  prompt_embeds [L,H], text_adds fp32 [F,H]
         (torch tensors or numpy arrays; they travel to the replica as numpy)."""
         from .sampling_params import SamplingParams
@@ -240,7 +269,9 @@ class ReplicaPool:
         as_np = lambda t: np.asarray(t.detach().float().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
         msg = (_CMD_ADD, rid, as_np(prompt_embeds), as_np(text_adds), int(max_frames), _sp_dict(tsp), _sp_dict(psp))
         with self._lock:
-            self._sinks[rid] = queue.Queue()
+            if rid in self._sinks:
+                raise ValueError(f"request id {rid!r} is already in use")
+            self._sinks[rid] = _sink if _sink is not None else queue.Queue()
             self._live.add(rid)
             self._backlog.append(msg)
             self._place_locked()
@@ -260,6 +291,9 @@ class ReplicaPool:
             sink.put((_END, "cancelled"))
 
     def _pump_results(self):
+        """The one thread that reads the replicas' messages: a frame message carries the codes of all streams of a
+        replica; they are handed to the streams' sinks here (async consumers of one event loop in one callback), and
+        the places of streams that ended are given to what waits in the router."""
         while True:
             try:
                 item = self._res_q.get(timeout=0.5)
@@ -268,21 +302,41 @@ class ReplicaPool:
                     return
                 self._reap()
                 continue
-            if item[0] == "__replica__":
+            if item[0] != _MSG_FRAMES:
                 continue
-            rid, frame, reason = item
+            _, _idx, rids, codes, ended = item
+            self.frame_messages += 1
+            self.router_cpu_seconds = time.thread_time()       # CPU time of this thread so far (load reports)
+            out = []
             with self._lock:
-                if rid not in self._live:                  # cancelled: the replica's late messages are dropped
-                    continue
-                sink = self._sinks.get(rid)
-                if frame is _END:
+                for k, rid in enumerate(rids):
+                    if rid in self._live:                      # (cancelled: the replica's late frames are dropped)
+                        sink = self._sinks.get(rid)
+                        if sink is not None:
+                            out.append((sink, (codes[k].tolist(), None)))
+                for rid, reason in ended:
+                    if rid not in self._live:
+                        continue
                     self._live.discard(rid)
                     i = self._where.pop(rid, None)
                     if i is not None:
                         self._load[i] -= 1
+                    sink = self._sinks.get(rid)
+                    if sink is not None:
+                        out.append((sink, (_END, reason)))
+                if ended:
                     self._place_locked()
-            if sink is not None:
-                sink.put((frame, reason))
+            by_loop: dict = {}
+            for sink, payload in out:
+                if isinstance(sink, _AsyncSink):
+                    by_loop.setdefault(sink.loop, []).append((sink.q, payload))
+                else:
+                    sink.put(payload)
+            for loop, batch in by_loop.items():
+                try:
+                    loop.call_soon_threadsafe(_put_all, batch)
+                except RuntimeError:                           # that loop has been closed
+                    pass
 
     def _reap(self):
         """A replica process that has gone away (crash, kill) takes its streams with it: they end with an error
@@ -338,14 +392,14 @@ class ReplicaPool:
         return self.frames(self.submit(prompt_embeds, text_adds, max_frames, **kw))
 
     async def generate_async(self, prompt_embeds, text_adds, max_frames: int, **kw):
-        """Async generator of frames: the blocking queue reads run in the default executor, so the event loop stays
-        free for other requests."""
-        rid = self.submit(prompt_embeds, text_adds, max_frames, **kw)
-        sink = self._sinks[rid]
-        loop = asyncio.get_running_loop()
+        """Async generator of frames.  The stream's frames arrive in an asyncio.Queue of the caller's event loop, put
+        there by the result thread: any number of streams may wait at once (no executor thread per stream), and a
+        replica that goes away ends the stream with an error (the reaper puts the end marker)."""
+        sink = _AsyncSink(asyncio.get_running_loop())
+        rid = self.submit(prompt_embeds, text_adds, max_frames, _sink=sink, **kw)
         try:
             while True:
-                frame, reason = await loop.run_in_executor(None, sink.get)
+                frame, reason = await sink.q.get()
                 if frame is _END:
                     if reason and reason not in ("finished", "cancelled"):
                         raise RuntimeError(f"stream {rid}: {reason}")

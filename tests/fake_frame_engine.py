@@ -90,3 +90,35 @@ class FakePollingFrameEngine(FakeFrameEngine):
                 poll()
             self._in_step = False
         return out
+
+
+class FakeLateJoinFrameEngine(FakePollingFrameEngine):
+    """The same, with admissions that do not join at once: a stream admitted without waiting stays in `streams` but
+    takes no part in the next `LATE` frames (the real engine's `Stream.active == False`: its prefill still runs beside
+    the frames, or waits behind another group's prefill)."""
+    LATE = 2
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.late_frames = 0
+
+    def add_streams(self, requests, wait=True):
+        before = set(self.streams)
+        out = super().add_streams(requests, wait=wait)
+        if not wait:
+            for sid in set(self.streams) - before:
+                self.streams[sid].hold = self.LATE
+        return out
+
+    def step(self, poll=None):
+        held = {sid: s for sid, s in self.streams.items() if getattr(s, "hold", 0) > 0}
+        for sid in held:                             # not part of this frame
+            del self.streams[sid]
+        try:
+            out = super().step(poll=poll)
+        finally:
+            for sid, s in held.items():
+                s.hold -= 1
+                self.late_frames += 1
+                self.streams[sid] = s
+        return out

@@ -15,9 +15,12 @@ class _S:
 
 
 class FakeEngine:
-    def __init__(self, tag=0, max_streams=2, step_seconds=0.002, fail_on=None, die_on=None):
+    def __init__(self, tag=0, max_streams=2, step_seconds=0.002, fail_on=None, die_on=None, paced=False):
         self.tag, self.max_streams, self.step_seconds, self.fail_on = tag, max_streams, step_seconds, fail_on
         self.die_on = die_on
+        # paced: frames on a fixed schedule (frame k ends at start + k * step_seconds; a late wake-up shortens the next
+        # wait), so that the offered rate of a load test is exactly streams / step_seconds
+        self.paced, self._deadline = paced, None
         self.streams = {}
         self.visible = os.environ.get("HIP_VISIBLE_DEVICES")
 
@@ -33,7 +36,15 @@ class FakeEngine:
         self.streams.pop(sid, None)
 
     def step(self):
-        time.sleep(self.step_seconds)
+        if self.paced:
+            now = time.perf_counter()
+            if self._deadline is None or now - self._deadline > 10 * self.step_seconds:      # first frame, or after idling
+                self._deadline = now
+            self._deadline += self.step_seconds
+            if self._deadline > now:
+                time.sleep(self._deadline - now)
+        else:
+            time.sleep(self.step_seconds)
         out = {}
         for sid, s in list(self.streams.items()):
             if self.fail_on is not None and s.key == self.fail_on:

@@ -283,3 +283,45 @@ def test_fused_loop_admits_requests_while_a_frame_is_in_flight(model_dir, monkey
     assert first == want(prompts[6])[0] and not left
     assert n > 0, "no request was admitted from the engine's hook"
     assert not iface._request_queues
+
+
+@pytest.mark.parametrize("admission", ["join", "beside"])
+def test_fused_loop_keeps_streams_whose_prefill_has_not_joined_yet(model_dir, monkeypatch, admission):
+    """A stream the engine has admitted without waiting is in `engine.streams` before it takes part in a frame (its
+    prefill runs beside the frames, or waits behind another group's).  A frame that brings nothing for it is not its
+    end: with a stand-in engine whose admissions join two frames late, every request still gets all its frames."""
+    import fake_frame_engine
+    from nano_qwen3tts_vllm.engine import frame_engine as FE
+    from nano_qwen3tts_vllm.interface import Qwen3TTSInterface
+    monkeypatch.setenv("QTTS_ASYNC_ENGINE", "fused")
+    monkeypatch.setenv("QTTS_ADMISSION", admission)
+    monkeypatch.setattr(FE, "FrameEngine", fake_frame_engine.FakeLateJoinFrameEngine)
+    iface = Qwen3TTSInterface.from_pretrained(model_dir)
+    iface.max_streams = 4
+    H = iface.model_config.talker_config.hidden_size
+    gen = torch.Generator().manual_seed(9)
+    prompts = [torch.randn(1, 3 + i, H, generator=gen) for i in range(6)]
+    trailing = torch.randn(1, 3, H, generator=gen)
+    pad = torch.randn(1, 1, H, generator=gen)
+
+    def want(pr):
+        key = int(pr.reshape(-1, H).float().abs().sum().item() * 7) % 1000
+        return [[(key + n * 17 + c) % 256 for c in range(16)] for n in range(fake_frame_engine.FRAMES)]
+
+    async def run():
+        await iface.start_zmq_tasks()
+
+        async def one(i):
+            await asyncio.sleep(0.004 * i)
+            return [f async for f in iface.generate_async(prompts[i], trailing, pad, None, request_id=f"r{i}")]
+        res = await asyncio.gather(*[one(i) for i in range(6)])
+        fe = iface._frame_engine
+        late, left = fe.late_frames, dict(fe.streams)
+        await iface.stop_zmq_tasks()
+        return res, late, left
+
+    res, late, left = asyncio.run(run())
+    assert late > 0, "no admission was held back"
+    for i, got in enumerate(res):
+        assert got == want(prompts[i]), (i, len(got))
+    assert not left and not iface._request_queues

@@ -45,7 +45,7 @@ def close(got, want, atol=4e-2, rtol=4e-2):
     return torch.allclose(got, want, atol=atol, rtol=rtol), float((got - want).abs().max())
 
 
-def judge(ids, logits, what, min_binding=0.0, fixture_ids=None):
+def judge(ids, logits, what, min_binding=0.0, fixture_ids=None, self_fed=False):
     """All picks acceptable to `logits` (the reference's / oracle's, same history); prints the counts."""
     ids, logits = torch.as_tensor(np.asarray(ids)).long(), torch.as_tensor(np.asarray(logits)).float()
     acc, bind, same = O.judge_picks(ids, logits, TOL_ULPS)
@@ -53,8 +53,21 @@ def judge(ids, logits, what, min_binding=0.0, fixture_ids=None):
     line = (f"[id parity] {what}: {n} picks, {int(bind.sum())} binding ({100.0 * int(bind.sum()) / n:.1f} %), "
             f"{int((~same).sum())} differ from the arg-max, {int((~acc).sum())} unacceptable")
     if fixture_ids is not None:
-        line += f"; {int((ids == torch.as_tensor(np.asarray(fixture_ids)).long()).sum())} of {n} ids equal the reference fixture"
+        fx = torch.as_tensor(np.asarray(fixture_ids)).long()
+        line += f"; {int((ids == fx).sum())} of {n} ids equal the reference fixture"
     print(line)
+    if fixture_ids is not None:
+        # Up to a row's first id that differs from the reference's, both runs share their history (the talker steps are
+        # fed the fixture's inputs throughout; a predictor burst feeds its own ids on): that pick must be one without a
+        # clear winner.  Measured on MI355X for all four fixture families: every id equals the reference's, which is
+        # the floor asserted here (a kernel change that moves a near-tie has to be looked at and the floor restated).
+        rows_ids, rows_fx, rows_bind = ids.reshape(-1, ids.shape[-1]), fx.reshape(-1, ids.shape[-1]), bind.reshape(-1, ids.shape[-1])
+        if not self_fed:
+            assert bool(((ids == fx) | ~bind).all()), f"{what}: binding picks {((ids != fx) & bind).nonzero().tolist()[:8]} differ from the reference fixture"
+        for i in range(rows_ids.shape[0]):
+            d = (rows_ids[i] != rows_fx[i]).nonzero().flatten()
+            assert not len(d) or not bool(rows_bind[i, int(d[0])]), f"{what}: row {i} leaves the reference's ids at pick {int(d[0])}, which has a clear winner"
+        assert bool((ids == fx).all()), f"{what}: ids {(ids != fx).nonzero().tolist()[:8]} differ from the reference fixture"
     assert bool(acc.all()), f"{what}: picks {(~acc).nonzero().tolist()[:8]} are neither the arg-max nor within {TOL_ULPS} bf16 steps of it"
     assert int(bind.sum()) >= min_binding * n, f"{what}: only {int(bind.sum())} of {n} picks were binding"
 
@@ -140,7 +153,7 @@ def test_predictor_engine_burst_matches_reference_fixture(setup, burst, monkeypa
     worst = float(ulp_distance(gpu_logits, ol).max())
     print(f"[logits] predictor {tag} burst={burst}: largest difference over 15 steps {worst:.2f} bf16 steps")
     assert worst <= LOGIT_ULPS
-    judge(got, ol, f"predictor burst={burst}, {tag}", MIN_BINDING[tag], fixture_ids=g["p_tokens"])
+    judge(got, ol, f"predictor burst={burst}, {tag}", MIN_BINDING[tag], fixture_ids=g["p_tokens"], self_fed=True)
     if np.array_equal(got, g["p_tokens"]):                        # same history as the reference's own run
         assert float(ulp_distance(gpu_logits, g["p_logits"]).max()) <= LOGIT_ULPS
     llm.exit()
@@ -272,7 +285,7 @@ def test_frame_loop_ids_match_reference_fixture(setup):
             talker.add_request([nxt.view(1, 1, -1)], greedy_sp(1), request_id=f"s{i}")
     tc, pc = oracle_cfgs(cfg)
     check_frames(frames, tw, tc, pw, pc, prompts, text_adds, f"two engines + API glue, {tag}", TOL_ULPS, MIN_BINDING[tag],
-                 fixture_frames=g["f_frames"])
+                 fixture_frames=g["f_frames"], fixture_tag=tag)
     talker.exit()
     pred.exit()
 
@@ -286,7 +299,9 @@ ICL8 = (90, 130, 110, 150, 100, 140, 120, 170)
                           ("1.7B", "bf16", (5, 9, 16, 33, 64, 100, 17, 40), "each"),
                           ("1.7B", "bf16", (7, 12, 20, 33, 48, 5, 9, 70, 16, 25, 31, 64), "each"),
                           ("1.7B", "fp8", ICL8, "packed"), ("1.7B", "bf16", (33, 200, 70), "beside"),
-                          ("1.7B", "bf16", (1020,), "each")])
+                          ("1.7B", "bf16", (1020,), "each"),
+                          ("1.7B", "bf16", tuple(5 + (7 * i) % 40 for i in range(20)), "packed"),
+                          ("0.6B", "bf16", tuple(4 + (5 * i) % 23 for i in range(36)), "packed")])
 def test_full_size_frames_match_oracle(size, weights, prompt_lens, admission, tmp_path, monkeypatch):
     """The released checkpoints' shapes (28 + 5 layers; 1.7B: hidden 2048 with the 2048 -> 1024 projection in front of
     the predictor, 0.6B: hidden 1024, no projection), random weights with spread-out heads, 2 streams (prompts of 9
@@ -303,7 +318,9 @@ def test_full_size_frames_match_oracle(size, weights, prompt_lens, admission, tm
     `weights="fp8"` the engine stores the layer GEMM weights as e4m3 with a power-of-two row scale and the oracle runs
     on exactly those dequantised weights, so the same bounds apply (the quantisation itself is not judged here).
     Eight streams are the benchmark's batch (one 16-row tile, half of it streams); twelve use the 16-row graphs with
-    every MFMA column a row of its own and four rows idle.
+    every MFMA column a row of its own and four rows idle.  Twenty (1.7B) and thirty-six (0.6B) streams run every decode
+    step as more than one row tile: the prompt GEMM kernels with the residual stream in fragment order and the norms
+    inside the GEMMs, decode attention writing fragment-order rows, the burst's 2-position prompts as 40 / 72 rows.
     admission="packed": eight voice-clone-length prompts (1010 rows together) admitted at once go through ONE packed
     prefill (add_streams) with fp8 weights; "beside": three prompts admitted without waiting are prefilled packed on the
     second HIP stream through the twin decoder and join the batch at the next frame.
@@ -361,4 +378,4 @@ def test_full_size_frames_match_oracle(size, weights, prompt_lens, admission, tm
               f"oracle with re-ordered sums within {float(noise.max()):.1f} (mean {float(noise.mean()):.3f})")
         assert float(d.mean()) <= 1.5 * float(noise.mean()) + 0.02 and float(d.max()) <= 2.0 * float(noise.max()) + 2.0
     check_frames(got, tw, tc, pw, pc, prompts, text_adds, f"frame engine at {size} shapes, {weights} weights, prompts {prompt_lens} admitted {admission}", tol_ulps=8.0, min_binding=0.7,
-                 max_unacceptable=2, oracle_result=r)
+                 max_unacceptable=2, oracle_result=r, noise_result=ra)

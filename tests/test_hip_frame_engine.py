@@ -52,7 +52,7 @@ def test_frame_engine_matches_fixture(tmp_path, tag, eager):
     fe.exit()
     tc, pc = oracle_cfgs(cfg)
     r = check_frames(got, tw, tc, pw, pc, prompts, text_adds, f"frame engine {tag} eager={eager}", TOL_ULPS, MIN_BINDING[tag],
-                     fixture_frames=g["f_frames"])
+                     fixture_frames=g["f_frames"], fixture_tag=tag)
     gt = torch.stack([torch.stack(t[:NF]) for t in t_logits])
     gh = torch.stack([torch.stack(h[:NF]) for h in hidden])
     gp = torch.stack(p_logits, 1)

@@ -32,7 +32,7 @@ def model(tmp_path_factory):
         tc, pc = oracle_cfgs(cfg)
         got = np.array(got_by_stream, dtype=np.int64)
         check_frames(got, tw, tc, pw, pc, [prompts[i] for i in streams], text[list(streams)], what, 2.0, 0.9,
-                     fixture_frames=g["f_frames"][list(streams)])
+                     fixture_frames=g["f_frames"][list(streams)], fixture_tag="sharp")
     return d, prompts, text, check
 
 

@@ -24,9 +24,12 @@ for _name, (_res, _args) in {
     "qtts_tune_prompt_attention": (None, [_i]),
     "qtts_tune_rows": (None, [_i]),
     "qtts_tune_rows_tm": (None, [_i]),
+    "qtts_tune_rows_norm": (None, [_i, _i]),
+    "qtts_tune_rows_tm1": (None, [_i]),
     "qtts_tune_shared_prologue": (None, [_i]),
     "qtts_debug_linear": (None, [_i]),
     "qtts_debug_linear_trace": (None, [_p]),
+    "qtts_debug_linear_rows": (_i, [_p, _i, _i, _p, _p, C.c_float, _p, _p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "qtts_debug_grid_barrier": (_i, [_p, _i, _i, _i, _i, _i, _i, _p]),
 }.items():
     _fn = getattr(hip.lib, _name)

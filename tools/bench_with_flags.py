@@ -12,6 +12,11 @@ if os.environ.get("QTTS_TUNE_T"):
     hip.lib.qtts_tune_linear(0, int(os.environ["QTTS_TUNE_T"]))         # decode GEMM: workgroups per CU x 64 as the tile-loop target
 if os.environ.get("QTTS_ROWS_TM"):
     hip.lib.qtts_tune_rows_tm(int(os.environ["QTTS_ROWS_TM"]))
+if os.environ.get("QTTS_ROWS_NORM"):                                    # "on[,max rows]": prompt GEMMs normalise their rows themselves
+    v = [int(t) for t in os.environ["QTTS_ROWS_NORM"].split(",")]
+    hip.lib.qtts_tune_rows_norm(v[0], v[1] if len(v) > 1 else 1 << 30)
+if os.environ.get("QTTS_ROWS_TM1"):
+    hip.lib.qtts_tune_rows_tm1(int(os.environ["QTTS_ROWS_TM1"]))
 sys.argv = ["bench.py"] + sys.argv[1:]
 import bench
 bench.main()

@@ -399,6 +399,44 @@ def rows():
                   f"   hot {hot:7.2f} us", flush=True)
 
 
+def rowsn():
+    """Prompt GEMMs that consume normalised rows, at the predictor's and the talker's shapes, rows in fragment order:
+    the rows normalised inside the GEMM from sum-of-squares partials (norm) against rows that arrive normalised
+    (plain) and the stand-alone RMSNorm launch that makes them; then the GEMMs that finish residual rows, with and
+    without the fragment-order epilogue + partial sums.  Cold weights (one matrix per launch, 28 in turn), in a graph."""
+    shapes = [("qkv pred", 4096, 1024, 0), ("gate_up pred", 6144, 1024, 1), ("head pred", 2048, 1024, 0),
+              ("qkv 1.7B", 4096, 2048, 0), ("gate_up 1.7B", 12288, 2048, 1)]
+    nl = 28
+    only = os.environ.get("QTTS_ROWS_ONLY")
+    for name, N, K, sw in shapes:
+        if only and only not in name:
+            continue
+        ws_w = [(torch.randn(N * K // 4, device=dev) * 0.02).bfloat16().repeat(4) for _ in range(nl)]
+        nw = torch.ones(K, device=dev).bfloat16()
+        for M in [int(v) for v in os.environ.get("QTTS_ROWS", "32,64").split(",")]:
+            M16 = (M + 15) // 16 * 16
+            x = (torch.randn(M16, K, device=dev) * 0.5).bfloat16()
+            ssq = torch.rand(M16, K // 16, device=dev) + 0.5
+            out = torch.empty(M16, N // 2 if sw else N, dtype=torch.bfloat16, device=dev)
+            xn = torch.empty_like(x)
+
+            def call(w, norm):
+                hip.check(hip.lib.qtts_debug_linear_rows(hip.ptr(x), K, 1, hip.ptr(ssq) if norm else None, hip.ptr(nw) if norm else None, 1e-6,
+                                                         hip.ptr(w), None, 0, 0, hip.ptr(out), N // 2 if sw else N, 0, None, M, N, K, sw, hip.stream()))
+
+            def normk():
+                hip.check(hip.lib.qtts_rmsnorm(hip.ptr(x), K, hip.ptr(nw), 1e-6, hip.ptr(xn), K, M, K, hip.stream()))
+            res = {}
+            for label, fn in (("plain", lambda: [call(w, False) for w in ws_w]), ("norm", lambda: [call(w, True) for w in ws_w]),
+                              ("rmsnorm+plain", lambda: [(normk(), call(w, False)) for w in ws_w])):
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    fn()
+                    gr = hip.Graph.capture(fn)
+                res[label] = timed(lambda: gr.launch(), nl)
+            print(f"{name:13s} M={M:4d}: " + "  ".join(f"{k} {v:6.2f} us" for k, v in res.items()), flush=True)
+
+
 def rowtrace():
     """Timestamps inside one prompt GEMM launch (gate/up shape): per workgroup, when the multiplications of tile i
     were issued and when its reduction barrier opened (100 MHz device clock)."""
@@ -413,8 +451,23 @@ def rowtrace():
     buf = torch.zeros(1024 * 32, dtype=torch.int64, device=dev)
     hip.lib.qtts_debug_linear(int(os.environ.get("QTTS_LINEAR_DBG", "0")))
 
+    normed = os.environ.get("QTTS_ROWS_NORM") == "1"        # rows normalised inside the GEMM (fragment-order rows)
+    if os.environ.get("QTTS_ROWS_K"):                          # the predictor's shapes: K = 1024
+        K = int(os.environ["QTTS_ROWS_K"])
+        N = {"gate_up": 6144, "qkv": 4096}[which]
+        ws = [(torch.randn(N * K // 4, device=dev) * 0.02).bfloat16().repeat(4) for _ in range(4)]
+        x = (torch.randn(M + 16, K, device=dev) * 0.5).bfloat16()[:M]
+        out = torch.empty(M + 16, N, dtype=torch.bfloat16, device=dev)
+    ssq = torch.rand(M + 16, K // 16, device=dev) + 0.5
+    nw = torch.ones(K, device=dev).bfloat16()
+
     def call(w):
-        if which == "gate_up":
+        if normed or os.environ.get("QTTS_ROWS_K"):
+            sw = int(which == "gate_up")
+            hip.check(hip.lib.qtts_debug_linear_rows(hip.ptr(x), K, 1, hip.ptr(ssq) if normed else None, hip.ptr(nw) if normed else None,
+                                                     1e-6, hip.ptr(w), None, 0, 0, hip.ptr(out), N // 2 if sw else N, 0, None, M, N, K, sw,
+                                                     hip.stream()))
+        elif which == "gate_up":
             hip.linear_swiglu(x, w, I, out=out)
         elif which == "down":
             hip.linear_ws(x, w, N, out=out)
@@ -439,7 +492,7 @@ def rowtrace():
     act = t[:, 1] > 0
     t = t[act]
     t0 = t[:, 0].min()
-    print(f"{which} M={M}: {int(act.sum())} active workgroups; start spread {t[:, 0].max() - t0:.0f} ns; last end {t[:, 31].max() - t0:.0f} ns")
+    print(f"{which} M={M} K={K} norm={int(normed)}: {int(act.sum())} active workgroups; start spread {t[:, 0].max() - t0:.0f} ns; last end {t[:, 31].max() - t0:.0f} ns")
     for it in range(15):
         a, b = t[:, 1 + 2 * it], t[:, 2 + 2 * it]
         ok = a > 0
@@ -517,4 +570,4 @@ def prefill():
 
 
 if __name__ == "__main__":
-    {"prefill": prefill, "prefill_batch": prefill_batch, "decode_eager": decode_eager, "rows": rows, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "mall": mall, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
+    {"prefill": prefill, "prefill_batch": prefill_batch, "decode_eager": decode_eager, "rows": rows, "rowsn": rowsn, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "mall": mall, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
