@@ -227,6 +227,10 @@ class FrameEngine:
                              f"{tuple(prompt_embeds.shape)} and {tuple(text_adds.shape)}")
         if L > self.tr.max_rows:
             raise ValueError(f"prompt of {L} tokens: the engine was built for at most {self.tr.max_rows} prompt rows per step")
+        if sid is not None and sid in self.streams:
+            # (a second stream under the same id would take over the dict entry: the first one's row and KV blocks
+            # could never be handed back)
+            raise ValueError(f"stream id {sid!r} is already in use")
         row = next((i for i, s in enumerate(self.rows) if s is None), None)
         if row is None:
             raise NoCapacity("all stream rows are taken")
@@ -296,7 +300,7 @@ class FrameEngine:
                 for i, s in enumerate(group):
                     self._pre_temps[i] = s.tsp.temperature
                 hip.check(hip.lib.qtts_sample_topk(hip.ptr(tr.pre_logits), tr.vocab, hip.ptr(self._pre_temps), self.top_k,
-                                                   tr.rng_seed, tr.next_rng_offset() + (1 << 40),
+                                                   tr.rng_seed, tr.next_rng_offset(),      # (the offset _pick would take: same first code either way)
                                                    hip.ptr(self._pre_drawn), n, tr.vocab, hip.stream()),
                           "sample_topk")
             for i, s in enumerate(group):

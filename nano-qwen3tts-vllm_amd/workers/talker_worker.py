@@ -47,28 +47,29 @@ def serve(talker_llm, recv, send, device=None) -> int:
 
 def run_talker_worker(command_connect_addr: str, result_connect_addr: str, model_path: str, *,
                       gpu_memory_utilization: float = 0.9, enforce_eager: bool = False,
-                      tensor_parallel_size: int = 1) -> None:
+                      tensor_parallel_size: int = 1, engine_factory: str | None = None) -> None:
+    """The worker process's body (reference: P/workers/talker_worker.py:42-145): build the engine, connect to the API
+    process's command and result addresses (`tcp://` -> ZeroMQ as the reference, `pipe://` -> workers/transport.py),
+    serve until shutdown.  engine_factory ("module:callable", called with the model path and the engine keywords)
+    replaces TalkerLLM - stand-in engines for tests of the process and transport plumbing."""
+    from .transport import open_worker_channels
+    if engine_factory:
+        import importlib
+        mod, _, attr = engine_factory.partition(":")
+        talker_llm = getattr(importlib.import_module(mod), attr)(model_path, enforce_eager=enforce_eager,
+                                                                 tensor_parallel_size=tensor_parallel_size)
+    else:
+        from ..interface import _compute_memory_split
+        from ..llm import TalkerLLM
+        mem = _compute_memory_split(model_path, gpu_memory_utilization)
+        talker_llm = TalkerLLM(model_path, enforce_eager=enforce_eager, tensor_parallel_size=tensor_parallel_size,
+                               gpu_memory_utilization=min(mem["talker_util"], 0.85),
+                               process_gpu_memory_fraction=mem["process_gpu_memory_fraction"])
+    recv, send, close = open_worker_channels(command_connect_addr, result_connect_addr)
     try:
-        import zmq
-    except ImportError as e:
-        raise ImportError("pyzmq is required for the talker worker process") from e
-    from ..interface import _compute_memory_split
-    from ..llm import TalkerLLM
-    mem = _compute_memory_split(model_path, gpu_memory_utilization)
-    talker_llm = TalkerLLM(model_path, enforce_eager=enforce_eager, tensor_parallel_size=tensor_parallel_size,
-                           gpu_memory_utilization=min(mem["talker_util"], 0.85),
-                           process_gpu_memory_fraction=mem["process_gpu_memory_fraction"])
-    ctx = zmq.Context()
-    pull, push = ctx.socket(zmq.PULL), ctx.socket(zmq.PUSH)
-    for s, addr in ((pull, command_connect_addr), (push, result_connect_addr)):
-        s.setsockopt(zmq.LINGER, 0)
-        s.connect(addr)
-    try:
-        serve(talker_llm, pull.recv, push.send)
+        serve(talker_llm, recv, send)
     finally:
-        pull.close()
-        push.close()
-        ctx.term()
+        close()
         try:
             talker_llm.exit()
         except Exception:
@@ -84,10 +85,12 @@ def main():
     p.add_argument("--gpu_memory_utilization", type=float, default=0.9)
     p.add_argument("--enforce_eager", action="store_true")
     p.add_argument("--tensor_parallel_size", type=int, default=1)
+    p.add_argument("--engine_factory", default=None)
     a = p.parse_args()
     logging.basicConfig(level=logging.INFO)
     run_talker_worker(a.command_connect, a.result_connect, a.model_path, gpu_memory_utilization=a.gpu_memory_utilization,
-                      enforce_eager=a.enforce_eager, tensor_parallel_size=a.tensor_parallel_size)
+                      enforce_eager=a.enforce_eager, tensor_parallel_size=a.tensor_parallel_size,
+                      engine_factory=a.engine_factory)
 
 
 if __name__ == "__main__":

@@ -367,9 +367,9 @@ def test_full_size_frames_match_oracle(size, weights, prompt_lens, admission, tm
         tw = {k: (O.quantize_fp8_rows(v)[2] if "_proj.weight" in k else v) for k, v in tw.items()}
         pw = {k: (O.quantize_fp8_rows(v)[2] if "_proj.weight" in k else v) for k, v in pw.items()}
     tc, pc = oracle_cfgs(cfg)
-    r = O.frame_loop_logits(tw, tc, pw, pc, prompts, text_adds, NF, forced=got)
+    r = O.frame_loop_logits(tw, tc, pw, pc, prompts, text_adds, NF, forced=got, num_blocks=max(32, S + 4))
     with O.other_summation_order():
-        ra = O.frame_loop_logits(tw, tc, pw, pc, prompts, text_adds, NF, forced=got)
+        ra = O.frame_loop_logits(tw, tc, pw, pc, prompts, text_adds, NF, forced=got, num_blocks=max(32, S + 4))
     gt = torch.stack([torch.stack(t[:NF]) for t in t_logits])      # [S,NF,V]
     gp = torch.stack(p_logits, 1)                                   # [S,NF,15,Vp]
     for name, mine, ref, alt in (("talker", gt, r["t_logits"], ra["t_logits"]), ("predictor", gp, r["p_logits"], ra["p_logits"])):

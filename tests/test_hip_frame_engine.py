@@ -260,7 +260,43 @@ def test_step_finishes_a_stream_at_its_frame_budget(tmp_path):
         from nano_qwen3tts_vllm.sampling_params import SamplingParams
         fe.add_stream(torch.zeros(4, H), torch.zeros(1, H), max_frames=2,
                       talker_sampling=SamplingParams(temperature=1.0, max_tokens=1, do_sample=True, top_k=20))
+    # a stream id that is in use is refused (the second stream would orphan the first one's row and KV blocks)
+    c = fe.add_stream(torch.zeros(4, H), torch.zeros(1, H), max_frames=2, sid="same")
+    with pytest.raises(ValueError, match="already in use"):
+        fe.add_stream(torch.zeros(4, H), torch.zeros(1, H), max_frames=2, sid="same")
+    fe.remove_stream(c)
+    assert len(fe.talker.scheduler.block_manager.free_block_ids) == free0 and fe.rows == [None, None]
     fe.exit()
+
+
+def test_a_sampling_request_draws_the_same_codes_whichever_way_it_is_admitted(tmp_path, monkeypatch):
+    """With a fixed sampler seed (QTTS_SEED) a sampling request's ids do not depend on the admission mode: prefilled
+    between two frames (wait=True) or on the second stream beside them (wait=False), its first code is drawn at the same
+    RNG offset, and the frames that follow draw from the same device-side counter."""
+    from nano_qwen3tts_vllm.engine.frame_engine import FrameEngine
+    from nano_qwen3tts_vllm.sampling_params import SamplingParams
+    monkeypatch.setenv("QTTS_SEED", "1234")
+    cfg, sd, tw, pw = golden_weights("tiny", 11)
+    json.dump(cfg, open(os.path.join(tmp_path, "config.json"), "w"))
+    H = cfg["talker_config"]["hidden_size"]
+    gen = torch.Generator().manual_seed(8)
+    prompt, text = torch.randn(7, H, generator=gen) * 0.5, torch.randn(6, H, generator=gen) * 0.3
+    sp = dict(talker_sampling=SamplingParams(temperature=1.0, max_tokens=1, do_sample=True, top_k=50),
+              predictor_sampling=SamplingParams(temperature=0.9, max_tokens=17, do_sample=True, top_k=50))
+    runs = []
+    for wait in (True, False):
+        fe = FrameEngine(str(tmp_path), max_streams=2, max_text_frames=8, talker_weights=tw, predictor_weights=pw,
+                         num_kvcache_blocks=4, max_num_batched_tokens=1024, codec_eos=None)
+        sid = fe.add_stream(prompt, text, max_frames=5, wait=wait, **sp)
+        frames = []
+        while fe.streams:
+            frames += list(fe.step().values())
+        fe.exit()
+        runs.append(frames)
+        assert len(frames) == 5
+    assert runs[0] == runs[1]
+    greedy_run = runs[0][0][0]
+    assert any(fr != runs[0][0] for fr in runs[0][1:]) and 0 <= greedy_run < cfg["talker_config"]["vocab_size"]
 
 
 @pytest.mark.parametrize("join", [True, False])

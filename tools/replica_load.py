@@ -5,7 +5,7 @@ frames out.  Reports delivered against offered frames per second and the CPU sha
     python tools/replica_load.py [replicas=8] [streams_per_replica=8] [frames=300] [step_ms=2.5] [async|sinks]
 
 async: every stream is consumed by a coroutine of one event loop (generate_async), as an API server does.
-sinks: the frames are left in the streams' queues and counted at the end - the router thread by itself (hundreds of
+sinks: every stream's consumer only counts and timestamps its frames inside the router thread - the router by itself (hundreds of
 streams at 400 frames a second each are more than one Python event loop can wake coroutines for; an API process per
 few replicas, the reference's own `uvicorn --workers N` hint (examples/server.py:6), is the answer there, not the router).
 """
@@ -20,6 +20,23 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+class _CountingSink:
+    """A stream's consumer reduced to what the measurement needs: when its first and last frame came, how many."""
+
+    def __init__(self):
+        self.n, self.first, self.last, self.reason = 0, None, None, None
+
+    def put(self, item):
+        frame, reason = item
+        if frame is None:
+            self.reason = reason
+            return
+        self.last = time.perf_counter()
+        if self.first is None:
+            self.first = self.last
+        self.n += 1
+
+
 def run(n_replicas=8, streams=8, frames=300, step_s=0.0025, consumers="async"):
     import torch
     from nano_qwen3tts_vllm.replicas import ReplicaPool
@@ -29,39 +46,40 @@ def run(n_replicas=8, streams=8, frames=300, step_s=0.0025, consumers="async"):
     total = n_replicas * streams
     text = torch.zeros(1, 8)
     prompt = torch.zeros(2, 8)
-    stamps = {}
     try:
+        # every replica serves one short stream first (its first admission imports torch: seconds, not part of the load)
+        for rid in [pool.submit(prompt, text, 3, request_id=f"warm{i}") for i in range(n_replicas)]:
+            list(pool.frames(rid))
+        cpu0, msg0 = pool.router_cpu_seconds, pool.frame_messages
         if consumers == "async":
             async def main():
                 async def one(i):
-                    n, first = 0, None
+                    n, first, last = 0, None, None
                     async for _ in pool.generate_async(prompt, text, frames, request_id=f"s{i}"):
+                        last = time.perf_counter()
                         if first is None:
-                            first = time.perf_counter()
+                            first = last
                         n += 1
-                    return n, first, time.perf_counter()
+                    return n, first, last
                 return await asyncio.gather(*(one(i) for i in range(total)))
             res = asyncio.run(main())
-            got = sum(r[0] for r in res)
-            t_first, t_last = min(r[1] for r in res), max(r[2] for r in res)
         else:
-            rids = [pool.submit(prompt, text, frames, request_id=f"s{i}") for i in range(total)]
-            sinks = [pool._sinks[r] for r in rids]
-            while sinks[0].empty():
-                time.sleep(0.0005)
-            t_first = time.perf_counter()
-            while pool.load() != [0] * n_replicas:           # every stream has ended (its end marker went through the router)
-                time.sleep(0.002)
-            t_last = time.perf_counter()
-            got = sum(sk.qsize() - 1 for sk in sinks)
-        cpu = pool.router_cpu_seconds
-        msgs = pool.frame_messages
+            sinks = [_CountingSink() for _ in range(total)]
+            for i, sk in enumerate(sinks):
+                pool.submit(prompt, text, frames, request_id=f"s{i}", _sink=sk)
+            deadline = time.perf_counter() + 20 * frames * step_s + 30
+            while any(sk.reason is None for sk in sinks) and time.perf_counter() < deadline:
+                time.sleep(0.005)
+            res = [(sk.n, sk.first, sk.last) for sk in sinks]
+        cpu, msgs = pool.router_cpu_seconds - cpu0, pool.frame_messages - msg0
     finally:
         pool.close()
-    wall = t_last - t_first
+    got = sum(r[0] for r in res)
+    wall = max(r[2] for r in res) - min(r[1] for r in res)
     offered = total / step_s
-    # the first frame's own step is not inside [first frame, last frame]
-    delivered = (got - total) / wall if wall > 0 else 0.0
+    # a stream's own rate between its first and its last frame, summed over the streams: what the consumers were
+    # delivered per second while they were being served (the streams do not all start in the same frame)
+    delivered = sum((r[0] - 1) / (r[2] - r[1]) for r in res if r[0] > 1)
     return {"replicas": n_replicas, "streams_per_replica": streams, "frames_per_stream": frames, "consumers": consumers,
             "frames_delivered": got, "frames_expected": total * frames, "offered_frames_per_s": round(offered),
             "delivered_frames_per_s": round(delivered), "ratio": round(delivered / offered, 4),
