@@ -82,51 +82,100 @@ def algorithmic_bytes_per_frame(cfg, B, mean_ctx, weights="bf16", folded=False):
     return 2 * talker + 2 * n_gen * pred_step + B * mean_ctx * kv_t + B * pred_ctx * kv_p - saved
 
 
-DOMINANT = "linear2_kernel<8,1,true,1> (talker RMSNorm + gate/up GEMM + SwiGLU launch)"
+# The launches of a frame that the event hook can time in place (qtts_model_set_layer_events): family -> (model,
+# which, what it is).  Algorithmic bytes: the launch's weights (+ rows in and out), or the K/V rows attention reads.
+LAUNCH_FAMILIES = [
+    ("talker norm + gate/up + SwiGLU", "talker", 3), ("talker down_proj + residual", "talker", 4),
+    ("talker norm + qkv", "talker", 1), ("talker o_proj + residual", "talker", 2),
+    ("talker q/k-norm + RoPE + store + attention", "talker", 5), ("talker final norm + codec head", "talker", 6),
+    ("predictor norm + gate/up + SwiGLU", "predictor", 3), ("predictor down_proj + residual", "predictor", 4),
+    ("predictor norm + qkv", "predictor", 1), ("predictor o_proj + residual", "predictor", 2),
+    ("predictor q/k-norm + RoPE + store + attention", "predictor", 5), ("predictor final norm + head", "predictor", 6),
+]
 
 
-def dominant_bytes(fe, B):
-    """Algorithmic bytes of one launch of the dominant kernel: the layer's gate/up weights once, the B input rows, the
-    norm weight and the B output rows."""
-    tr = fe.tr
-    H, I = tr.shape.hidden_size, tr.shape.intermediate_size
-    fp8 = tr.decoder.weight_dtype == "fp8"
-    return 2 * I * H * (1 if fp8 else 2) + (2 * I * 4 if fp8 else 0) + B * H * 2 + B * I * 2
+def launch_bytes_and_counts(fe, B, mean_ctx, folded):
+    """Per launch family: (algorithmic bytes of one launch, launches per frame)."""
+    fp8 = fe.tr.decoder.weight_dtype == "fp8"
+    wb = 1 if fp8 else 2
+    out = {}
+    for tag, runner in (("talker", fe.tr), ("predictor", fe.pr)):
+        sh = runner.shape
+        H, I, L = sh.hidden_size, sh.intermediate_size, sh.num_layers
+        A, KVW = sh.num_heads * sh.head_dim, sh.num_kv_heads * sh.head_dim
+        steps = 1 if tag == "talker" else fe.pr.n_gen
+        rows = B                                        # (the burst's first step has 2 B rows: counted as B)
+        ctx = mean_ctx if tag == "talker" else (2 + fe.pr.n_gen) / 2.0
+        n = L * steps
+        out[f"{tag} norm + gate/up + SwiGLU"] = (2 * I * H * wb + rows * (H + I) * 2, n)
+        out[f"{tag} down_proj + residual"] = (I * H * wb + rows * (I + 2 * H) * 2, n)
+        out[f"{tag} norm + qkv"] = ((A + 2 * KVW) * H * wb + rows * (H + A + 2 * KVW) * 2,
+                                    n - ((fe.pr.n_gen - 1) if (tag == "predictor" and folded) else 0))
+        out[f"{tag} o_proj + residual"] = (A * H * wb + rows * (A + 2 * H) * 2, n)
+        out[f"{tag} q/k-norm + RoPE + store + attention"] = (int(rows * ctx * 2 * KVW * 2), n)
+        out[f"{tag} final norm + " + ("codec head" if tag == "talker" else "head")] = (runner.vocab * H * 2 + rows * (H + runner.vocab) * 2, steps)
+    return out
 
 
-def time_dominant_kernel_in_frames(fe, frames=30):
-    """Device time of the path's largest kernel - the fused RMSNorm + gate/up GEMM + SwiGLU launch of a talker layer -
-    measured where it runs: while whole frames are generated (the codes graph, then the talker step's launches) that
-    launch of every layer carries two HIP events as its start / stop events on the engine's stream
-    (qtts_model_set_layer_events), whose elapsed time is the kernel's own execution time.  Returns (mean seconds, median seconds, samples).  The
-    timed region of the benchmark runs without the events; this pass follows it with the same streams."""
+def time_launches_in_frames(fe, frames=6):
+    """Device time of every launch family of LAUNCH_FAMILIES where it runs: while whole frames are generated eagerly on
+    the engine's stream, launch `which` of every layer of one model carries two HIP events as its start / stop events
+    (qtts_model_set_layer_events -> hipExtLaunchKernelGGL), whose elapsed time is the kernel's own execution time in
+    its real place in the frame, weights cold.  One family at a time.  Returns {family: (mean s, median s, samples)}.
+    (For the predictor the events keep the last burst step's five launches of each frame.)"""
     from nano_qwen3tts_vllm import hip
     import ctypes
     tr = fe.tr
-    nl = tr.shape.num_layers
-    begin = [torch.cuda.Event(enable_timing=True) for _ in range(nl)]
-    end = [torch.cuda.Event(enable_timing=True) for _ in range(nl)]
-    samples = []
     bs = fe._bucket()
+    out = {}
+    generated = 0
     with tr.on_stream():
-        for e in begin + end:                       # an event's handle exists once it has been recorded
-            e.record()
-        arr = ctypes.c_void_p * nl
-        hip.check(hip.lib.qtts_model_set_layer_events(tr.decoder._h, 3, arr(*[e.cuda_event for e in begin]),
-                                                      arr(*[e.cuda_event for e in end])), "set_layer_events")
-        try:
-            fe._setup_predictor_meta(bs)
-            for f in range(frames):
-                fe._launch_codes(bs)
-                fe._talker_part(bs, fe._max_ctx_bucket(extra_frames=f + 1))      # eager launches, gate/up with events
-                tr.stream.synchronize()
-                if f >= 2:
-                    samples += [b.elapsed_time(e) * 1e-3 for b, e in zip(begin, end)]
-        finally:
-            hip.check(hip.lib.qtts_model_set_layer_events(tr.decoder._h, 0, None, None), "set_layer_events")
-    for s in fe.streams.values():                   # these frames advanced the streams' contexts like any others
-        s.frames.extend([[0] * 16] * frames)
-    return statistics.fmean(samples), statistics.median(samples), len(samples)
+        fe._setup_predictor_meta(bs)
+        for name, model, which in LAUNCH_FAMILIES:
+            dec = (fe.tr if model == "talker" else fe.pr).decoder
+            nl = dec.shape.num_layers
+            n_ev = 1 if which == 6 else nl
+            begin = [torch.cuda.Event(enable_timing=True) for _ in range(nl)]
+            end = [torch.cuda.Event(enable_timing=True) for _ in range(nl)]
+            for e in begin + end:                       # an event's handle exists once it has been recorded
+                e.record()
+            arr = ctypes.c_void_p * nl
+            hip.check(hip.lib.qtts_model_set_layer_events(dec._h, which, arr(*[e.cuda_event for e in begin]),
+                                                          arr(*[e.cuda_event for e in end])), "set_layer_events")
+            samples = []
+            try:
+                for f in range(frames):
+                    fe._codes_part(bs)                   # eager launches (the graphs' launches cannot carry events)
+                    fe._talker_part(bs, fe._max_ctx_bucket(extra_frames=generated + 1))
+                    generated += 1
+                    tr.stream.synchronize()
+                    if f >= 1:
+                        samples += [b.elapsed_time(e) * 1e-3 for b, e in list(zip(begin, end))[:n_ev]]
+            finally:
+                hip.check(hip.lib.qtts_model_set_layer_events(dec._h, 0, None, None), "set_layer_events")
+            out[name] = (statistics.fmean(samples), statistics.median(samples), len(samples))
+    for s in fe.streams.values():                       # these frames advanced the streams' contexts like any others
+        s.frames.extend([[0] * 16] * generated)
+    return out, generated
+
+
+def host_cost_per_frame(fe, frames=40):
+    """What one frame costs the host through the serving call: wall time of FrameEngine.step, the part of it the host
+    is busy (enqueueing the frame's two graphs, reading the codes, bookkeeping - not waiting), and the process's CPU
+    time per frame with the admission hook polled (step(poll=...): the replica processes' form, sleeping between
+    polls)."""
+    res = {}
+    for label, poll in (("step", None), ("step_polling", lambda: None)):
+        fe.host_busy_s, fe.host_frames = 0.0, 0
+        fe.step(poll=poll)
+        fe.host_busy_s, fe.host_frames = 0.0, 0
+        c0, t0 = time.process_time(), time.perf_counter()
+        for _ in range(frames):
+            fe.step(poll=poll)
+        wall, cpu = time.perf_counter() - t0, time.process_time() - c0
+        res[label] = {"ms_per_frame": wall / frames * 1e3, "host_enqueue_ms_per_frame": fe.host_busy_s / max(fe.host_frames, 1) * 1e3,
+                      "host_cpu_ms_per_frame": cpu / frames * 1e3}
+    return res
 
 
 def cpu_baseline(cfg, tw, pw, B, frames, prompt_len):
@@ -155,7 +204,7 @@ def pmc_traffic():
     """HBM bytes per launch of the dominant kernel as stored in profiles/ by the rocprofv3 PMC passes over
     tools/microbench.py dominant (FETCH_SIZE and WRITE_SIZE collected separately, FETCH_SIZE doubled as gfx950
     requires) - a stored figure: hardware counters cannot be read from inside this process.  None when absent."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["traffic_bytes_per_launch"], f"profiles/{name}"
@@ -171,7 +220,8 @@ def profiler_duration():
     events include."""
     import glob
     import re
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_summary_*.txt")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_bench_summary_*.txt")) or
+                       glob.glob(os.path.join(ROOT, "profiles", "r02_bench_summary_*.txt")), reverse=True):
         try:
             m = re.search(r"grid \(131072, 1\): calls\s+\d+ avg\s+([0-9.]+) us", open(path).read())
             if m:
@@ -323,7 +373,7 @@ def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed, ad
             "note": "prefill and admission inside the timed region; first chunk = arrival -> the stream's first 16-code frame on the host"}
 
 
-ROOFLINE_FRAMES = 30
+ROOFLINE_FRAMES = 6 * len(LAUNCH_FAMILIES) + 2 * 42      # frames generated after the timed region (launch timing, host cost)
 ARRIVAL_FRAMES = 125          # 10 s of audio per stream
 ARRIVAL_GAP_S = 0.050
 
@@ -453,10 +503,28 @@ def main():
         tokens = whole_job_tokens(B, args.steps, world)
         value = tokens / elapsed
         mean_ctx = sum(prompt_lens) / B + 1 + args.warmup + 1 + args.steps / 2
-        folded = bool(getattr(fe.pr, "fold", False)) and B <= 16
+        folded = bool(getattr(fe.pr, "fold", False))
         bytes_frame = algorithmic_bytes_per_frame(cfg, B, mean_ctx, args.weights, folded)
-        kmean, kmedian, ksamples = time_dominant_kernel_in_frames(fe, ROOFLINE_FRAMES)
-        kbytes = dominant_bytes(fe, B)
+        timed, _ = time_launches_in_frames(fe, 6)
+        per = launch_bytes_and_counts(fe, B, mean_ctx, folded)
+        by_launch = []
+        for name, _model, _which in LAUNCH_FAMILIES:
+            mean_s, median_s, n = timed[name]
+            nbytes, count = per[name]
+            if mean_s < 2e-7:              # (steps of more than 16 rows run the prompt kernels, which carry no events)
+                continue
+            by_launch.append({"launch": name, "per_frame": count, "us": mean_s * 1e6, "us_median": median_s * 1e6,
+                              "us_per_frame": mean_s * 1e6 * count, "bytes_per_launch": nbytes,
+                              "achieved_GBps": nbytes / mean_s / 1e9, "frac": nbytes / mean_s / HBM_PEAK, "launches_timed": n})
+        by_launch.sort(key=lambda r: -r["us_per_frame"])
+        if not by_launch:                                    # nothing could be timed in place: the frame as a whole
+            by_launch = [{"launch": "whole frame", "per_frame": 1, "us": ms_per_step * 1e3, "us_median": ms_per_step * 1e3,
+                          "us_per_frame": ms_per_step * 1e3, "bytes_per_launch": bytes_frame,
+                          "achieved_GBps": bytes_frame / (ms_per_step * 1e-3) / 1e9, "frac": bytes_frame / (ms_per_step * 1e-3) / HBM_PEAK,
+                          "launches_timed": args.steps}]
+        top = by_launch[0]                                   # the family with the largest summed time per frame
+        talker_gu = next((r for r in by_launch if r["launch"] == "talker norm + gate/up + SwiGLU"), top)
+        host = host_cost_per_frame(fe, 40)
         stored = args.weights == "bf16" and args.size == "1.7B" and B == 8       # what the stored figures were taken on
         traffic, traffic_src = pmc_traffic() if stored else (None, None)
         prof_us, prof_src = profiler_duration() if stored else (None, None)
@@ -474,18 +542,31 @@ def main():
                                    + "; `arrivals`: the same engine under staggered arrivals with prefill inside the timed region",
                        "streams_per_gpu": B, "replicas": world},
             "rtf": ms_per_step * 1e-3 / FRAME_SECONDS,
+            "host_enqueue_ms_per_frame": host["step"]["host_enqueue_ms_per_frame"],
             "first_chunk_ms_p50": statistics.median(first_frame_ms) + frame0_ms,
             "prefill_ms": first_frame_ms,
             "frame_roofline": {"bound": "hbm", "bytes_per_frame": bytes_frame,
                                "achieved": bytes_frame / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                "unit": "GB/s", "frac": bytes_frame / (ms_per_step * 1e-3) / HBM_PEAK},
-            "roofline": {"bound": "hbm", "kernel": DOMINANT,
-                         "achieved": kbytes / kmean / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": kbytes / kmean / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-                         "bytes_per_launch": kbytes, "us_per_launch": kmean * 1e6, "us_per_launch_median": kmedian * 1e6,
-                         "launches_timed": ksamples, "us_per_launch_profiler": prof_us, "profiler_source": prof_src,
-                         "how": "HIP start/stop events bound to that launch of each of the 28 layers (hipExtLaunchKernelGGL on "
-                                "the engine's stream) while frames are generated, right after the timed region"},
+            "roofline": {"bound": "hbm", "kernel": top["launch"] + f" ({top['per_frame']} launches per frame: the family with the largest summed time)",
+                         "achieved": top["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": top["frac"], "traffic": None,
+                         "bytes_per_launch": top["bytes_per_launch"], "us_per_launch": top["us"], "us_per_launch_median": top["us_median"],
+                         "launches_timed": top["launches_timed"],
+                         "how": "HIP start/stop events bound to that launch of every layer (hipExtLaunchKernelGGL on the engine's "
+                                "stream) while frames are generated eagerly, right after the timed region; `by_launch`: every "
+                                "launch family of the frame the same way, sorted by time per frame",
+                         "largest_launch": {"kernel": "linear2_kernel<8,1,true,1> (talker RMSNorm + gate/up GEMM + SwiGLU launch: the most bytes per launch)",
+                                            "achieved": talker_gu["achieved_GBps"], "frac": talker_gu["frac"], "us_per_launch": talker_gu["us"],
+                                            "bytes_per_launch": talker_gu["bytes_per_launch"], "traffic": traffic, "traffic_source": traffic_src,
+                                            "us_per_launch_profiler": prof_us, "profiler_source": prof_src},
+                         "by_launch": by_launch},
+            "host": {"host_enqueue_ms_per_frame": host["step"]["host_enqueue_ms_per_frame"],
+                     "serving_ms_per_frame": host["step"]["ms_per_frame"],
+                     "polling": host["step_polling"],
+                     "note": "FrameEngine.step(): host time per frame not spent waiting (two graph launches, codes read-back, "
+                             "bookkeeping); polling: the replica processes' form, the admission hook polled while the frame runs "
+                             "(host_cpu_ms_per_frame = process CPU time, sleeps between polls excluded)"},
         }
         if arrivals is not None:
             out["arrivals"] = arrivals

@@ -271,7 +271,7 @@ int qtts_model_set_layer_fp8(qtts_model_t *m, int layer, const void *input_norm_
                              const void *w_down_fp8, const float *w_down_scales);
 
 int qtts_model_set_final_norm(qtts_model_t *m, const void *w);
-/* Measurement hook: from now on every decode step of `m` (up to 16 rows) launches GEMM number `which` of layer l with
+/* Measurement hook: from now on every decode step of `m` (up to 16 rows) launches kernel number `which` of layer l with
  * begin[l] / end[l] (hipEvent_t, n_layers of each, created by the caller with timing enabled; the arrays are copied)
  * as the kernel's own start / stop events (hipExtLaunchKernelGGL), so hipEventElapsedTime(begin[l], end[l]) after
  * the stream has drained is that kernel's execution time in place, between the launches it really follows and
@@ -282,6 +282,8 @@ int qtts_model_set_final_norm(qtts_model_t *m, const void *w);
 #define QTTS_LAUNCH_O_PROJ 2     /* o_proj + residual */
 #define QTTS_LAUNCH_GATE_UP 3    /* post-attention norm + gate/up projection + SwiGLU */
 #define QTTS_LAUNCH_DOWN 4       /* down_proj + residual */
+#define QTTS_LAUNCH_ATTENTION 5  /* q/k norm + RoPE + KV store + paged decode attention (the fused decode launch) */
+#define QTTS_LAUNCH_HEAD 6       /* final norm + output head of qtts_model_forward_logits* (events of index 0) */
 int qtts_model_set_layer_events(qtts_model_t *m, int which, void *const *begin, void *const *end);
 int qtts_model_set_rope(qtts_model_t *m, const void *cos, const void *sin, int max_pos);
 /* kv: [2, n_layers, num_blocks, 256, n_kv_heads, 128] bf16 (P/engine/model_runner/base.py:158-164). */

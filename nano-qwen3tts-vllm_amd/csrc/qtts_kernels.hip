@@ -224,6 +224,8 @@ static int g_share_prologue = 1;         // norm prologue shared between the lan
 static int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
 static int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention takes the MFMA kernel for prompts
 static int g_rows_tm = 0;                // row tiles per workgroup of the prompt GEMM (0 = chosen per shape)
+static int g_attn_wide = 0;              // decode attention: 0 = per shape, 1 = 128-token workgroups, 2 = 256-token ones
+extern "C" void qtts_tune_attn_wide(int mode) { g_attn_wide = mode; }
 static int g_rows_tm1 = 1;               // narrow prompt GEMMs may take one row tile per workgroup
 extern "C" void qtts_tune_rows_tm1(int on) { g_rows_tm1 = on; }
 static int g_rows_norm = 1;              // prompt GEMMs normalise their rows themselves (0: a norm launch in front, for A/B runs)
@@ -246,6 +248,7 @@ static constexpr int g_share_prologue = 1;         // norm prologue shared betwe
 static constexpr int g_sub_min_bytes = 32 << 10;   // smallest weight slice per workgroup when a tile is split over workgroups
 static constexpr int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention takes the MFMA kernel for prompts
 static constexpr int g_rows_tm = 0;                // row tiles per workgroup of the prompt GEMM (0 = chosen per shape)
+static constexpr int g_attn_wide = 0;              // decode attention: workgroup size chosen per shape
 static constexpr int g_rows_tm1 = 1;               // narrow prompt GEMMs may take one row tile per workgroup
 static constexpr int g_rows_norm = 1;              // prompt GEMMs normalise their rows themselves
 static constexpr int g_rows_norm_max = 1 << 30;    // most rows for which they do
@@ -2376,7 +2379,8 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
     // launches whose 128-token workgroups would outnumber the 256 CUs (1459 -> 1392 us at 900 tokens; in between the
     // narrower split is 2-3 % faster)
     const int ns128 = (max_context + ATT2_SPLIT - 1) / ATT2_SPLIT;
-    const bool wide = Hq / Hkv <= 2 && ns128 > 1 && (ns128 == 2 || (long)B * Hkv * ns128 > 256);
+    bool wide = Hq / Hkv <= 2 && ns128 > 1 && (ns128 == 2 || (long)B * Hkv * ns128 > 256);
+    if (g_attn_wide && Hq / Hkv <= 2 && ns128 > 1) wide = g_attn_wide == 2;       // (tuning build: 1 = 128-token workgroups, 2 = 256-token)
     const int split = wide ? 2 * ATT2_SPLIT : ATT2_SPLIT;
     const int ns = (max_context + split - 1) / split;
     QCHECK(ns == 1 || (partials && counters), "attention_decode_fused: workspace required for contexts > %d", split);
@@ -2393,7 +2397,7 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
     dim3 grid(B, Hkv, ns);
     if (uniform) {
         // the context length travels in the max_blocks argument's place
-#define QUNI(G_, IDS_) hipLaunchKernelGGL((attn_decode_fused_kernel<G_, 8, 4, IDS_, true>), grid, dim3(128), 0, s, a.context_lens, \
+#define QUNI(G_, IDS_) QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<G_, 8, 4, IDS_, true>), grid, dim3(128), 0, s, a.context_lens, \
                                           a.block_tables, a.positions, a.slots, a.qkv, max_context, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a)
         QCHECK(!row_ids || id_rows > 0, "attention_decode_fused: row ids without a table size");
         if (Hq / Hkv == 1) { if (row_ids) QUNI(1, true); else QUNI(1, false); }
@@ -2406,11 +2410,11 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
         // rows gathered from a table: built for the one-workgroup-per-(row, kv head) variants
         QCHECK(id_rows > 0 && (max_context <= 32 || Hq / Hkv == 4), "attention_decode_fused: gathered rows need max_context <= 32 (got %d)", max_context);
         switch (Hq / Hkv) {
-            case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 8, 4, true>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
-                    else hipLaunchKernelGGL((attn_decode_fused_kernel<1, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
-            case 2: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 8, 4, true>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
-                    else hipLaunchKernelGGL((attn_decode_fused_kernel<2, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
-            case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<4, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
+            case 1: if (max_context <= 32) QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<1, 8, 4, true>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+                    else QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<1, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
+            case 2: if (max_context <= 32) QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<2, 8, 4, true>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+                    else QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<2, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
+            case 4: QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<4, 16, ATT2_SPLIT / 16, true>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
             default: QFAIL(QTTS_EINVAL, "attention_decode_fused: unsupported q/kv head ratio %d", Hq / Hkv);
         }
         QLAUNCH();
@@ -2420,15 +2424,15 @@ static int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q
         // short contexts (the code predictor's 17 tokens) leave most of a 32-group workgroup idle: eight
         // 16-lane groups (two waves) of four tokens cover 32 tokens (burst 1669 us with sixteen groups of two tokens, 1664 us
         // with eight of four, 1712 us with four of eight; sixteen groups of eight tokens, 16 K/V requests per lane: 1788 us)
-        case 1: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 8, 4>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
-                else if (wide) hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32, 8>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
-                else hipLaunchKernelGGL((attn_decode_fused_kernel<1, 32>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+        case 1: if (max_context <= 32) QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<1, 8, 4>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+                else if (wide) QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<1, 32, 8>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+                else QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<1, 32>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                 break;
-        case 2: if (max_context <= 32) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 8, 4>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
-                else if (wide) hipLaunchKernelGGL((attn_decode_fused_kernel<2, 32, 8>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
-                else hipLaunchKernelGGL((attn_decode_fused_kernel<2, 32>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+        case 2: if (max_context <= 32) QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<2, 8, 4>), grid, dim3(128), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+                else if (wide) QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<2, 32, 8>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
+                else QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<2, 32>), grid, dim3(512), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a);
                 break;
-        case 4: hipLaunchKernelGGL((attn_decode_fused_kernel<4, 16>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
+        case 4: QTTS_LAUNCH_MAYBE_TIMED((attn_decode_fused_kernel<4, 16>), grid, dim3(256), 0, s, a.context_lens, a.block_tables, a.positions, a.slots, a.qkv, a.max_blocks, a.ld, a.Hq, a.Hkv, a.max_pos, a.nsplit, a); break;
         default: QFAIL(QTTS_EINVAL, "attention_decode_fused: unsupported q/kv head ratio %d", Hq / Hkv);
     }
     QLAUNCH();
@@ -3232,7 +3236,7 @@ extern "C" int qtts_model_set_layer_fp8(qtts_model_t *m, int layer, const void *
 
 extern "C" int qtts_model_set_layer_events(qtts_model_t *m, int which, void *const *begin, void *const *end) {
     QCHECK(m, "model_set_layer_events: null model");
-    QCHECK(which >= 0 && which <= QTTS_LAUNCH_DOWN, "model_set_layer_events: unknown launch %d", which);
+    QCHECK(which >= 0 && which <= QTTS_LAUNCH_HEAD, "model_set_layer_events: unknown launch %d", which);
     QCHECK(which == 0 || (begin && end), "model_set_layer_events: null event arrays");
     m->ev_which = 0;
     m->ev_begin.clear();
@@ -3339,7 +3343,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     // x_ids: x is a table of x_id_rows rows and row r of the step is x[x_ids[r]] (read in place by layer 0's qkv GEMM
     // and o_proj residual); qkv0_rows: a table of the same rows after layer 0's input norm and qkv GEMM, which then
     // is not launched
-    QCHECK(!x_ids || (x_id_rows > 0 && N <= 16 && !row_seq), "model_forward: gathered input rows are for decode steps of up to 16 rows");
+    QCHECK(!x_ids || (x_id_rows > 0 && !row_seq && (N <= 16 || qkv0_rows)), "model_forward: gathered input rows are for decode steps (beyond 16 rows: with a layer-0 qkv table)");
     QCHECK(!qkv0_rows || x_ids, "model_forward: a layer-0 qkv table needs row ids");
     if (!m->final_norm || !m->cosT || !m->kv || !m->ws) QFAIL(QTTS_ESTATE, "model_forward: model not fully configured");
     for (const LayerW &L : m->layers)
@@ -3348,7 +3352,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     // attention_decode_fused_impl
     const bool uniform = !pairs && !row_seq && !positions && !slot_mapping && !context_lens && !block_tables;
     QCHECK(x && hidden_out && (uniform || (positions && (pairs || (context_lens && block_tables)))), "model_forward: null pointer");
-    QCHECK(!uniform || (N <= m->num_blocks && N <= 16), "model_forward: rows without metadata need a KV block each (N=%d)", N);
+    QCHECK(!uniform || N <= m->num_blocks, "model_forward: rows without metadata need a KV block each (N=%d)", N);
     // pairs: rows (2i, 2i+1) are the two positions of a fresh sequence i; the head (required) runs on the second rows
     QCHECK(!pairs || (N % 2 == 0 && N <= 16 && !row_seq && !x_ids && head_w), "model_forward: bad 2-position prompt arguments");
     QCHECK(N > 0 && N <= m->ws_rows, "model_forward: N=%d exceeds workspace rows %d", N, m->ws_rows);
@@ -3384,13 +3388,26 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
     // finish residual rows (o_proj, a single-pass down_proj) leave every row's sum of squares per 16 columns behind:
     // the GEMM that consumes the rows normalised (gate/up, the next layer's qkv, the head) then computes the row
     // scale from those partials and normalises in registers, and the RMSNorm launch between the two is gone.
-    const bool n3 = frag && g_rows_norm && N <= g_rows_norm_max && linear_rows_norm_covers(H);
+    // Up to 64 rows at a hidden size of 2048 (beyond that the four-row-tile workgroups, whose registers leave no room
+    // for the normalisation, stream the weights faster than two-row-tile ones save launches: a 200-token prompt 2.89
+    // against 3.10 ms) and up to 256 rows at 1024.
+    const bool n3 = frag && g_rows_norm && N <= g_rows_norm_max && linear_rows_norm_covers(H) && N <= (H > 1024 ? 64 : 256);
     float *ssq = (float *)(m->ws + W.ssq);
     const float scale = 1.0f / sqrtf((float)m->head_dim);
     const size_t layer_kv = (size_t)m->num_blocks * QTTS_KV_BLOCK * Hkv * 128 * 2;   // bytes per layer per K or V
     const bf16_t *cur = (const bf16_t *)x;
     bool cur_frag = false, cur_ssq = false;            // `cur` in fragment order / its sums of squares are in `ssq`
     int rc;
+    // A step of more than 16 rows whose input rows come from a table (x_ids; with layer 0's qkv rows from their table):
+    // the prompt GEMM kernels take no row ids, so the rows are gathered once, into the buffer of the normalised rows
+    // (free until the first post-attention norm, by when layer 0's o_proj has read them as its residual rows), and
+    // the ids are used by layer 0's attention only.
+    const int64_t *res_ids0 = x_ids;
+    if (x_ids && split_norm) {
+        hipLaunchKernelGGL(embedding_gather_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, x_ids, xn, H, H, x_id_rows);
+        cur = xn;
+        res_ids0 = nullptr;
+    }
     const bool decode = row_seq == nullptr;           // one row per sequence: fused norm/RoPE/store/attention
     // Decode steps of 9..16 rows: every lane of a GEMM's activation requests carries a row of its own (no lanes to
     // share the prologue with, as up to 8 rows), so the two activations a layer produces for a plain prologue -
@@ -3406,7 +3423,9 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
         const LayerW &L = m->layers[l];
         char *kc = m->kv + (size_t)l * layer_kv;
         char *vc = m->kv + ((size_t)m->n_layers + l) * layer_kv;
-        if (split_norm) {
+        if (split_norm && l == 0 && qkv0_rows) {
+            // layer 0's normalised, projected rows come from the table
+        } else if (split_norm) {
             if (!xn_ready && cur_ssq) {
                 // the rows are normalised inside the GEMM
                 ActLayout lay = lay_in;
@@ -3435,6 +3454,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
                                            dfrag ? Hq * 128 / 32 : 0)))
                 return rc;
         } else if (decode) {
+            LayerEventScope ev(m, l, QTTS_LAUNCH_ATTENTION, stream);
             if ((rc = attention_decode_fused_impl(tab0 ? qkv0_rows : qkv, qkvw, L.q_norm, L.k_norm, m->eps, m->cosT, m->sinT,
                                                   m->max_pos, positions, slot_mapping, kc, vc, block_tables, max_blocks,
                                                   context_lens, max_context, scale, attn, Hq * 128, N, Hq, Hkv, att_ws,
@@ -3456,7 +3476,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
                 lay.ssq_out = ssq;
             }
             if ((rc = stack_linear(attn, Hq * 128, L.wo, L.s_o, cur, H, nullptr, 0.f, xa, H, N, H, Hq * 128, nullptr, 0, stream,
-                                   nullptr, nullptr, 0, nullptr, l == 0 ? x_ids : nullptr, x_id_rows, lay)))
+                                   nullptr, nullptr, 0, nullptr, l == 0 ? res_ids0 : nullptr, x_id_rows, lay)))
                 return rc;
         }
         if (split_norm) {
@@ -3515,6 +3535,7 @@ static int model_forward_impl(qtts_model_t *m, const void *x, const int64_t *pos
             return qtts_linear_fused(cur + H, 2 * H, nullptr, 0, head_w, nullptr, nullptr, 0, m->final_norm, m->eps, hidden_out, H,
                                      0, logits_out, vocab, N / 2, vocab, H, stream);
         // final RMSNorm folded into the head GEMM's prologue; the normalised rows are the returned hidden state
+        LayerEventScope ev(m, 0, QTTS_LAUNCH_HEAD, stream);
         if ((rc = qtts_linear_fused(cur, H, nullptr, 0, head_w, nullptr, nullptr, 0, m->final_norm, m->eps, hidden_out, H, 0,
                                     logits_out, vocab, N, vocab, H, stream))) return rc;
         return QTTS_OK;

@@ -20,6 +20,7 @@ void qtts_tune_shared_prologue(int on);             /* lane halves share the act
 void qtts_tune_prompt_attention(int min_rows);      /* rows from which prompts take the MFMA attention kernel */
 void qtts_debug_linear(int flags);                  /* bit 0: every tile reads weight tile 0; bit 1: no prompt GEMM; bit 5: no fused norm */
 void qtts_debug_linear_trace(long long *buf);       /* device buffer of per-workgroup timestamps, or NULL */
+void qtts_tune_attn_wide(int mode);                 /* decode attention: 0 per shape, 1 = 128-token workgroups, 2 = 256-token ones */
 void qtts_tune_rows_tm1(int on);                    /* narrow prompt GEMMs may take one row tile per workgroup */
 void qtts_tune_rows_norm(int on, int max_rows);     /* prompt GEMMs normalise their rows from the producer's partial sums (up to max_rows rows) */
 int qtts_debug_linear_rows(const void *x, int ldx, int xpacked, const float *ssq_in, const void *norm_w, float eps,

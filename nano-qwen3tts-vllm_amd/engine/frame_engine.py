@@ -19,6 +19,7 @@ work for embedding-fed sequences.
 from __future__ import annotations
 
 import contextlib
+import functools
 import os
 import time
 
@@ -27,9 +28,19 @@ import torch
 from .. import hip
 from ..llm import PredictorLLM, TalkerLLM
 from ..sampling_params import SamplingParams
+from .guards import SingleCaller
 from .sequence import Sequence
 
 CODEC_EOS = 2150        # hard-coded in the reference's API loop (P/interface.py:1233)
+
+
+def _single_caller(fn):
+    """A public engine call: one host thread at a time (engine/guards.py)."""
+    @functools.wraps(fn)
+    def inner(self, *a, **kw):
+        with self._one_caller:
+            return fn(self, *a, **kw)
+    return inner
 
 
 class NoCapacity(RuntimeError):
@@ -61,6 +72,7 @@ class FrameEngine:
                  predictor_weights=None, enforce_eager: bool = False, codec_eos: int | None = CODEC_EOS, top_k: int = 50,
                  **kw):
         kw = dict(kw)
+        self._one_caller = SingleCaller("FrameEngine")     # held by every public call (see engine/guards.py)
         self.top_k = top_k
         kw.setdefault("max_num_seqs", max(max_streams, 1))
         tkw = dict(kw, enforce_eager=enforce_eager)
@@ -123,6 +135,10 @@ class FrameEngine:
         self._talker_mark = None
         self._talker_pair = None
         self._talker_s = 0.0
+        self._codes_s = 0.0                # running estimate: launch of a frame -> its codes on the host (step(poll=))
+        # host time inside step() that was not spent waiting (enqueueing the frame's graphs, reading the codes, stream
+        # bookkeeping), and the number of step() calls it was collected over: what a replica costs its host per frame
+        self.host_busy_s, self.host_frames = 0.0, 0
         self._pred_meta_bs = None
         self._next_sid = 0
         # values of per-row metadata writes on their way to the device (_sync_row_to_device)
@@ -139,6 +155,7 @@ class FrameEngine:
             self.tr.stream.synchronize()
 
     # ---------------------------------------------------------------- admission
+    @_single_caller
     def add_stream(self, prompt_embeds: torch.Tensor, text_adds: torch.Tensor, max_frames: int,
                    talker_sampling: SamplingParams | None = None, predictor_sampling: SamplingParams | None = None,
                    sid: str | None = None, wait: bool = True) -> str:
@@ -158,6 +175,7 @@ class FrameEngine:
             self._prefill_detached([s])
         return s.sid
 
+    @_single_caller
     def add_streams(self, requests: list[dict], wait: bool = True) -> list:
         """Admits several requests at once (dicts of add_stream's arguments, without `wait`): their prompts are
         packed into ONE prefill (all rows of all prompts through each GEMM together - the reference's scheduler packs
@@ -376,6 +394,7 @@ class FrameEngine:
         if s is not None:
             st.d("tables")[row * mb:(row + 1) * mb].copy_(slot[4:4 + mb], non_blocking=True)
 
+    @_single_caller
     def remove_stream(self, sid: str):
         s = self.streams.pop(sid, None)
         if s is None:
@@ -479,6 +498,7 @@ class FrameEngine:
             g = self.graphs[key] = hip.Graph.capture(lambda: self._talker_part(bs, max_ctx))
         g.launch()
 
+    @_single_caller
     def capture_all(self, max_context: int | None = None) -> int:
         """Captures the graphs of every (batch bucket, context bucket) this engine can meet — one codes graph per
         batch bucket, one talker graph per (batch, context) bucket — so that no capture happens while streams are
@@ -501,6 +521,7 @@ class FrameEngine:
     def _bucket_for(self, n: int) -> int:
         return next(b for b in self.tr.graph_bs if b >= max(n, 1))
 
+    @_single_caller
     def run_frames(self, n: int) -> torch.Tensor:
         """Generate n frames for every active stream back to back (no EOS handling: the caller asked
         for exactly n; a stream with fewer than n frames left of its max_frames is an error, its KV blocks were
@@ -526,6 +547,7 @@ class FrameEngine:
                 s.frames.extend(out[:, s.row].tolist())
         return out
 
+    @_single_caller
     def step(self, poll=None) -> dict[str, list[int]]:
         """One frame for every active stream; streams whose talker id is the codec EOS finish
         without yielding that frame (as P/interface.py:1233-1239); a stream that has produced its max_frames
@@ -534,6 +556,8 @@ class FrameEngine:
         wait; a serving loop admits what has arrived meanwhile from it with add_stream(s)(wait=False), so a prompt's
         prefill starts beside the frame in flight instead of after the next time the loop gets round to looking.
         With poll the frame is also handed to the GPU as late as it can be without leaving it idle (see below)."""
+        t_in = time.perf_counter()
+        waited = 0.0                     # of this call: time the host spent waiting (for the GPU, or asleep between polls)
         if poll is not None and self._talker_mark is not None:
             # The talker step that closed the previous frame is still running (about a millisecond) and this frame's
             # codes cannot start before it ends: the frame is not committed to the GPU's queue until shortly before
@@ -543,7 +567,9 @@ class FrameEngine:
             deadline = begun + self._talker_s - self.LAUNCH_MARGIN_S
             while time.perf_counter() < deadline and not pair[1].query():
                 poll()
-                time.sleep(5e-5)
+                t_w = time.perf_counter()
+                time.sleep(self._poll_sleep(deadline - t_w))
+                waited += time.perf_counter() - t_w
         self._talker_mark = None
         if not self.streams or not self._activate_or_wait():
             return {}
@@ -564,13 +590,21 @@ class FrameEngine:
             if pair:
                 pair[1].record(torch.cuda.current_stream())
         if poll is None:
+            t_w = time.perf_counter()
             self._codes_event.synchronize()
+            waited += time.perf_counter() - t_w
         else:
+            # the codes are due one predictor burst after the launch (tracked like the talker step's duration)
+            due = time.perf_counter() + self._codes_s
+            t_launch = time.perf_counter()
             while True:
                 poll()
                 if self._codes_event.query():
                     break
-                time.sleep(5e-5)
+                t_w = time.perf_counter()
+                time.sleep(self._poll_sleep(due - t_w))
+                waited += time.perf_counter() - t_w
+            self._codes_s = 0.5 * self._codes_s + 0.5 * (time.perf_counter() - t_launch)
             # the codes are here, so this frame's talker step has just begun; how long it runs is taken from the
             # previous frame's (finished by now: this frame's codes came after it)
             if self._talker_pair is not None:
@@ -592,7 +626,17 @@ class FrameEngine:
             if len(s.frames) >= s.max_frames:
                 s.finished = True
                 self.remove_stream(s.sid)
+        self.host_busy_s += time.perf_counter() - t_in - waited
+        self.host_frames += 1
         return res
+
+    @staticmethod
+    def _poll_sleep(remaining: float) -> float:
+        """How long the host sleeps between two looks at the GPU (and calls of the poll hook) while it waits for an
+        event expected `remaining` seconds from now: 50 us when the event is about due - the wake-up then follows it
+        closely - and up to 200 us while it is still far away, so that a waiting replica leaves its core mostly idle
+        (eight replicas share one host) and a request that arrives meanwhile is still noticed within 0.2 ms."""
+        return 5e-5 if remaining < 1.5e-4 else min(2e-4, remaining - 1e-4)
 
     def exit(self):
         self.graphs.clear()

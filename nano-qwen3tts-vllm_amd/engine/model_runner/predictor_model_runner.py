@@ -249,7 +249,7 @@ class PredictorModelRunner(ModelRunner):
         for step in range(1, self.n_gen):
             tb = self.tables[step - 1]
             prev = hip.ptr(self.burst_tokens) + 8 * (step - 1) * bs
-            if self.fold and bs <= 16:               # one 16-row tile: the decode kernels (larger batches project per step)
+            if self.fold:                            # (more than 16 rows: the rows are gathered once per step, layer 0's qkv rows still come from their table)
                 xt, qt = self.x_tables[step - 1], self.qkv0_tables[step - 1]
                 if getattr(self, "_uniform_rows", False):
                     # row r is sequence r in KV block r and every row is at context step + 2: no metadata arrays, the

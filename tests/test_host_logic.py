@@ -108,3 +108,31 @@ def test_c_abi_exports_every_declared_symbol():
     # argument validation happens before any launch, so it can be exercised without a device
     assert hip.lib.qtts_linear(None, 0, None, None, None, 0, None, 0.0, None, 0, 1, 16, 32, None) == -1
     assert hip.lib.qtts_last_error().startswith(b"linear:")
+
+
+def test_single_caller_guard_is_reentrant_for_one_thread_and_refuses_a_second():
+    """engine/guards.py: the frame engine's public calls hold this guard - re-entrant for the thread inside (the poll
+    hook admits streams from within step), an error for another thread arriving meanwhile (two host threads would
+    interleave stream records and waits that are only safe in one host order)."""
+    import threading
+    from nano_qwen3tts_vllm.engine.guards import SingleCaller
+    g = SingleCaller("engine")
+    seen = []
+    with g:
+        with g:                                   # same thread, nested
+            seen.append("nested")
+
+        def other():
+            try:
+                with g:
+                    seen.append("entered")
+            except RuntimeError as e:
+                seen.append(str(e))
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+    assert seen[0] == "nested" and "another thread" in seen[1]
+    t = threading.Thread(target=other)            # free again once the first thread has left
+    t.start()
+    t.join()
+    assert seen[2] == "entered"

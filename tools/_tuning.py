@@ -26,6 +26,7 @@ for _name, (_res, _args) in {
     "qtts_tune_rows_tm": (None, [_i]),
     "qtts_tune_rows_norm": (None, [_i, _i]),
     "qtts_tune_rows_tm1": (None, [_i]),
+    "qtts_tune_attn_wide": (None, [_i]),
     "qtts_tune_shared_prologue": (None, [_i]),
     "qtts_debug_linear": (None, [_i]),
     "qtts_debug_linear_trace": (None, [_p]),
@@ -34,3 +35,21 @@ for _name, (_res, _args) in {
 }.items():
     _fn = getattr(hip.lib, _name)
     _fn.restype, _fn.argtypes = _res, _args
+
+
+def apply_env_flags():
+    """The dispatch switches of the tuning build, from the environment (A/B runs of one script)."""
+    e = os.environ
+    if e.get("QTTS_ROWS_NORM"):                     # "on[,max rows]": prompt GEMMs normalise their rows themselves
+        v = [int(t) for t in e["QTTS_ROWS_NORM"].split(",")]
+        hip.lib.qtts_tune_rows_norm(v[0], v[1] if len(v) > 1 else 1 << 30)
+    if e.get("QTTS_ROWS_TM1"):
+        hip.lib.qtts_tune_rows_tm1(int(e["QTTS_ROWS_TM1"]))
+    if e.get("QTTS_ATTN_WIDE"):
+        hip.lib.qtts_tune_attn_wide(int(e["QTTS_ATTN_WIDE"]))
+    if e.get("QTTS_ROWS_TM"):
+        hip.lib.qtts_tune_rows_tm(int(e["QTTS_ROWS_TM"]))
+    if e.get("QTTS_ROWS_MIN"):
+        hip.lib.qtts_tune_rows(int(e["QTTS_ROWS_MIN"]))
+    if e.get("QTTS_MFMA_ATTN_ROWS"):
+        hip.lib.qtts_tune_prompt_attention(int(e["QTTS_MFMA_ATTN_ROWS"]))

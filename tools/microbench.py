@@ -570,4 +570,5 @@ def prefill():
 
 
 if __name__ == "__main__":
+    _tuning.apply_env_flags()
     {"prefill": prefill, "prefill_batch": prefill_batch, "decode_eager": decode_eager, "rows": rows, "rowsn": rowsn, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "mall": mall, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
