@@ -226,7 +226,7 @@ static int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention
 static int g_rows_tm = 0;                // row tiles per workgroup of the prompt GEMM (0 = chosen per shape)
 static int g_attn_wide = 0;              // decode attention: 0 = per shape, 1 = 128-token workgroups, 2 = 256-token ones
 extern "C" void qtts_tune_attn_wide(int mode) { g_attn_wide = mode; }
-static int g_rows_tm1 = 1;               // narrow prompt GEMMs may take one row tile per workgroup
+static int g_rows_tm1 = 2;               // prompt GEMMs that may take one row tile per workgroup (0 none, 1 narrow plain outputs, 2 any)
 extern "C" void qtts_tune_rows_tm1(int on) { g_rows_tm1 = on; }
 static int g_rows_norm = 1;              // prompt GEMMs normalise their rows themselves (0: a norm launch in front, for A/B runs)
 static int g_rows_norm_max = 1 << 30;    // most rows for which they do
@@ -249,7 +249,7 @@ static constexpr int g_sub_min_bytes = 32 << 10;   // smallest weight slice per 
 static constexpr int g_mfma_attn_rows = 112;       // rows from which qtts_paged_attention takes the MFMA kernel for prompts
 static constexpr int g_rows_tm = 0;                // row tiles per workgroup of the prompt GEMM (0 = chosen per shape)
 static constexpr int g_attn_wide = 0;              // decode attention: workgroup size chosen per shape
-static constexpr int g_rows_tm1 = 1;               // narrow prompt GEMMs may take one row tile per workgroup
+static constexpr int g_rows_tm1 = 2;               // prompt GEMMs of up to four row tiles may take one row tile per workgroup
 static constexpr int g_rows_norm = 1;              // prompt GEMMs normalise their rows themselves
 static constexpr int g_rows_norm_max = 1 << 30;    // most rows for which they do
 #endif
@@ -1239,7 +1239,9 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
             if (tm == 3 && (ksw != 8 || kparts > 1)) continue;   // three row tiles: built for K = 2048 in one part
             if (tm > 2 && (mtiles <= 2 || ksw == 12)) continue;
             if (norm3 && tm > 2 && ksw == 8) continue;           // rows normalised in registers: two row tiles at K = 2048
-            if (tm == 1 && (ntiles > 128 || silu_pairs || kparts > 1 || mtiles > 4 || g_rows_tm1 == 0)) continue;
+            // (g_rows_tm1 == 1: narrow plain outputs only; 2: any single-part GEMM of up to four row tiles)
+            if (tm == 1 && (kparts > 1 || mtiles > 4 || g_rows_tm1 == 0 || (g_rows_tm1 == 1 && (ntiles > 128 || silu_pairs)))) continue;
+            if (tm == 1 && silu_pairs && ksw != 4 && ksw != 8) continue;
             const int c = plan(tm, nullptr);
             if (c < best) { best = c; TM = tm; }
         }
@@ -1268,12 +1270,16 @@ static bool launch_linear_rows(const LinArgs &a, bool silu_pairs, float *scratch
 #define QR(KSW_, TM_, EPI_) ok = launch_rows_inst<KSW_, TM_, EPI_>(grid, s, a, tpw, r)
 #define QRN(KSW_, TM_, EPI_) ok = launch_rows_inst<KSW_, TM_, EPI_, true>(grid, s, a, tpw, r)
     if (norm3) {
-        if (TM == 1) { if (ksw == 8) QRN(8, 1, 0); else QRN(4, 1, 0); }
+        if (TM == 1) { if (ksw == 8) { if (epi == 0) QRN(8, 1, 0); else QRN(8, 1, 1); } else { if (epi == 0) QRN(4, 1, 0); else QRN(4, 1, 1); } }
         else if (ksw == 8) { if (epi == 0) QRN(8, 2, 0); else QRN(8, 2, 1); }
         else if (TM == 2) { if (epi == 0) QRN(4, 2, 0); else QRN(4, 2, 1); }
         else { if (epi == 0) QRN(4, 4, 0); else QRN(4, 4, 1); }
     } else
-    if (TM == 1) { if (ksw == 12) QR(12, 1, 0); else if (ksw == 8) QR(8, 1, 0); else QR(4, 1, 0); }
+    if (TM == 1) {
+        if (ksw == 12) QR(12, 1, 0);
+        else if (ksw == 8) { if (epi == 0) QR(8, 1, 0); else QR(8, 1, 1); }
+        else { if (epi == 0) QR(4, 1, 0); else QR(4, 1, 1); }
+    }
     else if (ksw == 12) QR(12, 2, 0);
     else if (ksw == 8) {
         if (TM == 2) { if (epi == 0) QR(8, 2, 0); else if (epi == 1) QR(8, 2, 1); else QR(8, 2, 2); }

@@ -437,6 +437,52 @@ def rowsn():
             print(f"{name:13s} M={M:4d}: " + "  ".join(f"{k} {v:6.2f} us" for k, v in res.items()), flush=True)
 
 
+def attn():
+    """The talker's fused decode attention launch (q/k norm + RoPE + store + paged attention) at QTTS_ATTN_ROWS rows and
+    QTTS_ATTN_CTX tokens of context, cycling through 28 layers' caches inside one graph (cold K/V)."""
+    from nano_qwen3tts_vllm.models.hip_decoder import rope_tables
+    Hq, Hkv, nl = 16, 8, 28
+    for B in [int(v) for v in os.environ.get("QTTS_ATTN_ROWS", "8,32,64").split(",")]:
+        for ctx in [int(v) for v in os.environ.get("QTTS_ATTN_CTX", "150,290,400,500").split(",")]:
+            nb = (ctx + 255) // 256
+            nblk = B * nb
+            kc = torch.randn(nl, nblk, 256, Hkv, 128, device=dev, dtype=torch.bfloat16)
+            vc = torch.randn(nl, nblk, 256, Hkv, 128, device=dev, dtype=torch.bfloat16)
+            qkv = torch.randn(B, (Hq + 2 * Hkv) * 128, device=dev).bfloat16()
+            qw = torch.ones(128, device=dev).bfloat16()
+            ct, st = rope_tables(128, 1000000.0, 2048)
+            ct, st = ct.to(dev), st.to(dev)
+            bt = torch.zeros(B, 4, dtype=torch.int32)
+            for i in range(B):
+                bt[i, :nb] = torch.arange(i * nb, (i + 1) * nb)
+            bt = bt.to(dev)
+            lens = torch.tensor([max(1, ctx - (7 * i) % 40) for i in range(B)], dtype=torch.int32)
+            cl = lens.to(dev)
+            pos = lens.to(torch.int64).to(dev)
+            slots = torch.tensor([int(bt[i, (int(c) - 1) // 256]) * 256 + (int(c) - 1) % 256 for i, c in enumerate(lens)], dtype=torch.int32).to(dev)
+            out = torch.empty(B, Hq * 128, dtype=torch.bfloat16, device=dev)
+            ws = torch.zeros(hip.lib.qtts_attn_decode_workspace_bytes(B, Hq, Hkv, ctx), dtype=torch.uint8, device=dev)
+            line = f"attention B={B:3d} ctx={ctx:4d} ({B * ctx * Hkv * 512 / 1e6:6.1f} MB of K/V):"
+            for wide in (0, 1, 2):
+                hip.lib.qtts_tune_attn_wide(wide)
+
+                def run():
+                    for l in range(nl):
+                        hip.check(hip.lib.qtts_attention_decode_fused(hip.ptr(qkv), qkv.stride(0), hip.ptr(qw), hip.ptr(qw), 1e-6, hip.ptr(ct),
+                                                                      hip.ptr(st), 2048, hip.ptr(pos), hip.ptr(slots), hip.ptr(kc[l]), hip.ptr(vc[l]),
+                                                                      hip.ptr(bt), 4, hip.ptr(cl), ctx, 128 ** -0.5, hip.ptr(out), Hq * 128, B, Hq,
+                                                                      Hkv, hip.ptr(ws), hip.stream()))
+                sst = torch.cuda.Stream()
+                with torch.cuda.stream(sst):
+                    run()
+                    gr = hip.Graph.capture(run)
+                us = timed(lambda: gr.launch(), nl)
+                line += f"  {('per shape', '128-token workgroups', '256-token workgroups')[wide]} {us:6.2f} us"
+            hip.lib.qtts_tune_attn_wide(0)
+            print(line, flush=True)
+            del kc, vc
+
+
 def rowtrace():
     """Timestamps inside one prompt GEMM launch (gate/up shape): per workgroup, when the multiplications of tile i
     were issued and when its reduction barrier opened (100 MHz device clock)."""
@@ -571,4 +617,4 @@ def prefill():
 
 if __name__ == "__main__":
     _tuning.apply_env_flags()
-    {"prefill": prefill, "prefill_batch": prefill_batch, "decode_eager": decode_eager, "rows": rows, "rowsn": rowsn, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "mall": mall, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
+    {"prefill": prefill, "prefill_batch": prefill_batch, "decode_eager": decode_eager, "rows": rows, "rowsn": rowsn, "attn": attn, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "mall": mall, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
