@@ -167,7 +167,7 @@ class FrameEngine:
         joins the batch is the engine's `join_prefills` policy (see step).  One prefill at a time, in arrival order.
         Same launches, same ids either way.
         Raises NoCapacity (no free row / KV blocks now: try again when a stream has ended) or ValueError (can never
-        be served: too long, wrong shapes, a top_k the graphs were not captured for)."""
+        be served: too long, wrong shapes, a stream id that is in use)."""
         s = self._reserve(prompt_embeds, text_adds, max_frames, talker_sampling, predictor_sampling, sid)
         if wait:
             self._prefill_now([s])
@@ -232,10 +232,10 @@ class FrameEngine:
         """Checks the request, takes a row and the KV blocks of the stream's whole lifetime."""
         tsp = talker_sampling or SamplingParams(temperature=1.0, max_tokens=1)
         psp = predictor_sampling or SamplingParams(temperature=0.9, max_tokens=17)
-        for sp in (tsp, psp):
-            if sp.do_sample and sp.top_k != self.top_k:
-                raise ValueError(f"top_k={sp.top_k}: the frame graphs are captured for top_k={self.top_k} (the reference's "
-                                 f"sampler default, P/layers/sampler.py:15); build the engine with another top_k to change it")
+        # A request's own top_k is carried but not used, as in the reference: its sampler cuts at its default of 50
+        # whatever SamplingParams.top_k says (P/layers/sampler.py:15, P/engine/model_runner/base.py:236-241 hands the
+        # sampler temperatures only).  Every sampling row of this engine uses the engine's top_k (50 unless the engine
+        # was built with another).
         L = prompt_embeds.shape[-2]
         total = L + max_frames + 1
         if total > self.tr.config.max_model_len:

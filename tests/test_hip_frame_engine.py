@@ -256,10 +256,11 @@ def test_step_finishes_a_stream_at_its_frame_budget(tmp_path):
             seen[sid] += 1
     assert seen == {a: 3, b: 5} and not fe.streams and fe.step() == {}
     assert len(fe.talker.scheduler.block_manager.free_block_ids) == free0
-    with pytest.raises(ValueError, match="top_k"):
-        from nano_qwen3tts_vllm.sampling_params import SamplingParams
-        fe.add_stream(torch.zeros(4, H), torch.zeros(1, H), max_frames=2,
+    # a request's own top_k is accepted and ignored, as the reference's sampler ignores it (P/layers/sampler.py:15)
+    from nano_qwen3tts_vllm.sampling_params import SamplingParams
+    t = fe.add_stream(torch.zeros(4, H), torch.zeros(1, H), max_frames=2,
                       talker_sampling=SamplingParams(temperature=1.0, max_tokens=1, do_sample=True, top_k=20))
+    assert len([f for _ in range(2) for f in fe.step().values()]) == 2 and t not in fe.streams
     # a stream id that is in use is refused (the second stream would orphan the first one's row and KV blocks)
     c = fe.add_stream(torch.zeros(4, H), torch.zeros(1, H), max_frames=2, sid="same")
     with pytest.raises(ValueError, match="already in use"):

@@ -1,6 +1,5 @@
-"""Makes the measurement scripts use the -DQTTS_TUNING build of the library (csrc/libqtts_hip_tuning.so: dispatch
-thresholds as settable process-wide variables, in-kernel timestamps, the grid-barrier probe, the resident burst
-kernel).  Import this module before nano_qwen3tts_vllm.hip; the shipped library has none of these entry points.
+"""Makes the measurement scripts use the -DQTTS_TUNING build of the library (tools/libqtts_hip_tuning.so: dispatch
+thresholds as settable process-wide variables, in-kernel timestamps, the grid-barrier probe, a stand-alone prompt-GEMM entry).  Import this module before nano_qwen3tts_vllm.hip; the shipped library has none of these entry points.
 
     python nano-qwen3tts-vllm_amd/csrc/build.py --tuning      # once, in the build container
 """
@@ -10,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # QTTS_TUNING_LIB: another -DQTTS_TUNING build of the same source (an experiment compiled with extra -D flags)
-LIB = os.environ.get("QTTS_TUNING_LIB") or os.path.join(ROOT, "nano-qwen3tts-vllm_amd", "csrc", "libqtts_hip_tuning.so")
+LIB = os.environ.get("QTTS_TUNING_LIB") or os.path.join(ROOT, "tools", "libqtts_hip_tuning.so")
 if not os.path.exists(LIB):
     raise SystemExit(f"{LIB} is missing: build it with `python nano-qwen3tts-vllm_amd/csrc/build.py --tuning`")
 os.environ["QTTS_LIB"] = LIB

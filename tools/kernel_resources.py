@@ -1,9 +1,12 @@
-"""Prints VGPR / scratch / occupancy per kernel of csrc/qtts_kernels.hip (compile-only)."""
+"""Prints VGPR / scratch / occupancy per kernel of the library's translation units (compile-only); an argument
+selects the units whose name contains it (gemm, attention, glue, model)."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "nano-qwen3tts-vllm_amd", "csrc", "qtts_kernels.hip")
-out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-I", os.path.join(ROOT, "include"),
-                      "-Rpass-analysis=kernel-resource-usage", src, "-o", "/tmp/qtts_res.o"], capture_output=True, text=True).stderr
+CSRC = os.path.join(ROOT, "nano-qwen3tts-vllm_amd", "csrc")
+units = [u for u in ("qtts_gemm.hip", "qtts_attention.hip", "qtts_glue.hip", "qtts_model.hip") if len(sys.argv) < 2 or sys.argv[1] in u]
+out = "".join(subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-I", os.path.join(ROOT, "include"),
+                              "-I", CSRC, "-Rpass-analysis=kernel-resource-usage", os.path.join(CSRC, u), "-o", "/tmp/qtts_res.o"],
+                             capture_output=True, text=True).stderr for u in units)
 cur, rows = None, {}
 for line in out.splitlines():
     m = re.search(r"Function Name: (\S+)", line)

@@ -1,7 +1,7 @@
 #!/bin/bash
 set -e -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3rowsn; rm -rf $O; mkdir -p $O; cd $R
-for lib in $R/nano-qwen3tts-vllm_amd/csrc/libqtts_hip_tuning*.so; do
+for lib in $R/tools/libqtts_hip_tuning*.so; do
   echo "== $(basename $lib)" | tee -a $O/rowsn.txt
   QTTS_TUNING_LIB=$lib timeout -k 10 300 python3 -u tools/microbench.py rowsn >> $O/rowsn.txt 2>> $O/err.log
   for cfg in "gate_up 32 2048" "gate_up 32 1024" "qkv 32 1024"; do

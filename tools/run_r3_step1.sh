@@ -23,7 +23,7 @@ import json
 x=json.loads([l for l in open('$O/bench_prod_$S.json') if l.startswith('{')][-1])
 print('product library: streams', $S, 'ms/frame', round(x['ms_per_step'],3))"
 done
-QTTS_TUNING_LIB=$R/nano-qwen3tts-vllm_amd/csrc/libqtts_hip_tuning.so timeout -k 10 300 python3 -u tools/microbench.py rowsn > $O/rowsn.txt 2>> $O/err.log
+QTTS_TUNING_LIB=$R/tools/libqtts_hip_tuning.so timeout -k 10 300 python3 -u tools/microbench.py rowsn > $O/rowsn.txt 2>> $O/err.log
 cat $O/rowsn.txt
 timeout -k 10 900 python3 -u -m pytest -x -q --timeout 300 --timeout-method thread -m gpu -s tests/test_hip_engine.py tests/test_hip_frame_engine.py tests/test_hip_interface.py > $O/tests_main.log 2>&1 || { grep -a "id parity\|FAILED\|Error" $O/tests_main.log | tail -30; exit 1; }
 grep -a "id parity" $O/tests_main.log | cut -c1-250; tail -2 $O/tests_main.log
