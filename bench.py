@@ -200,34 +200,45 @@ def cpu_baseline(cfg, tw, pw, B, frames, prompt_len):
                        f"{frames} frames, {dt:.1f} s")
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel as stored in profiles/ by the rocprofv3 PMC passes over
-    tools/microbench.py dominant (FETCH_SIZE and WRITE_SIZE collected separately, FETCH_SIZE doubled as gfx950
-    requires) - a stored figure: hardware counters cannot be read from inside this process.  None when absent."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+PROFILE_ROUNDS = ("r03", "r02", "r01")
+
+
+def pmc_traffic(which="talker"):
+    """HBM bytes per launch of a decode gate/up launch (which: talker / predictor) as stored in profiles/ by the
+    rocprofv3 PMC passes over tools/microbench.py dominant (FETCH_SIZE and WRITE_SIZE collected separately,
+    FETCH_SIZE doubled as gfx950 requires) - a stored figure: hardware counters cannot be read from inside this
+    process.  (None, None) when absent."""
+    for rnd in PROFILE_ROUNDS:
+        name = f"{rnd}_pmc_traffic.json"
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["traffic_bytes_per_launch"], f"profiles/{name}"
+                d = json.load(f)
+            if which == "predictor":
+                d = d["predictor_gate_up"]
+            return d["traffic_bytes_per_launch"], f"profiles/{name}"
         except Exception:
             continue
     return None, None
 
 
-def profiler_duration():
-    """(average us, file) of the dominant launch in the committed rocprofv3 kernel trace of this same command
-    (profiles/r02_bench_summary_*.txt, the line of the 256-workgroup grid) - a stored figure, shown beside the live
-    one: the profiler's begin->end timestamps exclude the command processor's ~1 us around a kernel that the
-    events include."""
+def profiler_duration(which="talker"):
+    """(average us, file) of a decode gate/up launch (which: talker / predictor) in the committed rocprofv3 kernel
+    trace of this same command (profiles/rNN_bench_summary_*.txt, the first grid line of that kernel's section) - a
+    stored figure, shown beside the live one: the profiler's begin->end timestamps exclude what the command processor
+    spends around a kernel, which the events include."""
     import glob
     import re
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_bench_summary_*.txt")) or
-                       glob.glob(os.path.join(ROOT, "profiles", "r02_bench_summary_*.txt")), reverse=True):
-        try:
-            m = re.search(r"grid \(131072, 1\): calls\s+\d+ avg\s+([0-9.]+) us", open(path).read())
-            if m:
-                return float(m.group(1)), "profiles/" + os.path.basename(path)
-        except Exception:
-            continue
+    section = {"talker": "linear2_kernel<8, 1, true, 1,", "predictor": "linear2_kernel<8, 1, false, 1,"}[which]
+    for rnd in PROFILE_ROUNDS:
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{rnd}_bench_summary_*.txt")), reverse=True):
+            try:
+                text = open(path).read()
+                at = text.find(section + " by grid")
+                m = re.search(r"grid \(\d+, \d+\): calls\s+\d+ avg\s+([0-9.]+) us", text[at:]) if at >= 0 else None
+                if m:
+                    return float(m.group(1)), "profiles/" + os.path.basename(path)
+            except Exception:
+                continue
     return None, None
 
 
@@ -528,6 +539,10 @@ def main():
         stored = args.weights == "bf16" and args.size == "1.7B" and B == 8       # what the stored figures were taken on
         traffic, traffic_src = pmc_traffic() if stored else (None, None)
         prof_us, prof_src = profiler_duration() if stored else (None, None)
+        # the same two stored figures for the top family when it is the predictor's gate/up launch
+        top_model = "predictor" if top["launch"].startswith("predictor norm + gate/up") else "talker" if top is talker_gu else None
+        top_traffic, top_traffic_src = pmc_traffic(top_model) if stored and top_model else (None, None)
+        top_prof_us, top_prof_src = profiler_duration(top_model) if stored and top_model else (None, None)
         out = {
             "metric": f"codec tokens/sec at {B} concurrent streams per GPU (RTF alongside), Qwen3-TTS-{args.size}",
             "value": value, "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -550,12 +565,15 @@ def main():
                                "unit": "GB/s", "frac": bytes_frame / (ms_per_step * 1e-3) / HBM_PEAK},
             "roofline": {"bound": "hbm", "kernel": top["launch"] + f" ({top['per_frame']} launches per frame: the family with the largest summed time)",
                          "achieved": top["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": top["frac"], "traffic": None,
+                         "frac": top["frac"], "traffic": top_traffic, "traffic_source": top_traffic_src,
+                         "us_per_launch_profiler": top_prof_us, "profiler_source": top_prof_src,
                          "bytes_per_launch": top["bytes_per_launch"], "us_per_launch": top["us"], "us_per_launch_median": top["us_median"],
                          "launches_timed": top["launches_timed"],
                          "how": "HIP start/stop events bound to that launch of every layer (hipExtLaunchKernelGGL on the engine's "
-                                "stream) while frames are generated eagerly, right after the timed region; `by_launch`: every "
-                                "launch family of the frame the same way, sorted by time per frame",
+                                "stream) while frames are generated eagerly, right after the timed region (an event pair around "
+                                "one kernel includes the command processor's work around it, about 2 us that consecutive nodes "
+                                "of the frame graphs do not pay: us_per_launch_profiler is the kernel's own begin->end time); "
+                                "`by_launch`: every launch family of the frame the same way, sorted by time per frame",
                          "largest_launch": {"kernel": "linear2_kernel<8,1,true,1> (talker RMSNorm + gate/up GEMM + SwiGLU launch: the most bytes per launch)",
                                             "achieved": talker_gu["achieved_GBps"], "frac": talker_gu["frac"], "us_per_launch": talker_gu["us"],
                                             "bytes_per_launch": talker_gu["bytes_per_launch"], "traffic": traffic, "traffic_source": traffic_src,

@@ -235,20 +235,23 @@ def gridbar():
 
 
 def dominant():
-    """The dominant kernel of the path alone (talker RMSNorm + gate/up GEMM + SwiGLU launch, 1.7B shape, 8 rows),
-    cycling through 28 weight buffers — the workload the PMC traffic passes are collected on."""
-    B, H, I = 8, 2048, 6144
-    ws = [torch.randn(2 * I * H, device=dev).bfloat16() * 0.02 for _ in range(28)]
+    """A gate/up launch of the path alone (RMSNorm + gate/up GEMM + SwiGLU, 8 rows): the talker's at the 1.7B shape
+    cycling through 28 weight buffers, or with QTTS_DOMINANT=predictor the predictor's (hidden 1024, intermediate 3072)
+    cycling through 5 - the workloads the PMC traffic passes are collected on."""
+    pred = os.environ.get("QTTS_DOMINANT") == "predictor"
+    B, H, I, n = (8, 1024, 3072, 5) if pred else (8, 2048, 6144, 28)
+    ws = [torch.randn(2 * I * H, device=dev).bfloat16() * 0.02 for _ in range(n)]
     x = torch.randn(B, H, device=dev).bfloat16()
     nw = torch.ones(H, device=dev).bfloat16()
     out = torch.empty(B, I, dtype=torch.bfloat16, device=dev)
     st = torch.cuda.Stream()
+    reps = 280 // n
     with torch.cuda.stream(st):
-        for _ in range(10):
+        for _ in range(reps):
             for w in ws:
                 hip.linear_swiglu(x, w, I, norm_w=nw, out=out)
         st.synchronize()
-    print("launches", 280, "algorithmic bytes per launch", 2 * I * H * 2 + B * H * 2 + B * I * 2, flush=True)
+    print("launches", reps * n, "algorithmic bytes per launch", 2 * I * H * 2 + B * H * 2 + B * I * 2, flush=True)
     if os.environ.get("QTTS_DOMINANT_TIMED"):
         def run():
             for w in ws:

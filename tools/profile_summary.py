@@ -2,7 +2,7 @@
 
     python tools/profile_summary.py <dir with *_kernel_trace.csv and *_kernel_stats.csv> <out.txt> "<header line>"
 
-Besides the per-kernel totals it lists the dominant kernel's launches by grid (the decode launch bench.py times)
+Besides the per-kernel totals it lists the decode gate/up kernels' launches by grid (the decode launches bench.py times)
 and the launches of the run's last frame.
 """
 import collections
@@ -12,7 +12,9 @@ import os
 import statistics
 import sys
 
-DOMINANT = "linear2_kernel<8, 1, true, 1,"
+# the decode gate/up launches (RMSNorm + GEMM + SwiGLU) of the talker and of the predictor: the launch with the most
+# bytes, and the family with the largest summed time per frame
+DOMINANT = ("linear2_kernel<8, 1, true, 1,", "linear2_kernel<8, 1, false, 1,")
 
 
 def main():
@@ -30,15 +32,16 @@ def main():
         name = k.replace("void ", "")[:60]
         lines.append(f"{name:60s} calls {len(v):6d} avg {statistics.mean(v) / 1e3:8.2f} us  total {sum(v) / 1e6:8.2f} ms "
                      f"{100 * sum(v) / total:5.1f}%")
-    lines += ["", f"{DOMINANT} by grid (x = workgroups*512 threads):"]
-    by = collections.defaultdict(list)
-    for r in rows:
-        if DOMINANT in r["Kernel_Name"]:
-            by[(int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]))].append(dur(r))
-    smallest = min(by) if by else None
-    for k, v in sorted(by.items()):
-        lines.append(f"  grid {k}: calls {len(v):5d} avg {statistics.mean(v) / 1e3:7.2f} us  median {statistics.median(v) / 1e3:7.2f} us"
-                     f"  min {min(v) / 1e3:7.2f} us" + ("   <- the decode launch bench.py times" if k == smallest else ""))
+    for dom in DOMINANT:
+        lines += ["", f"{dom} by grid (x = workgroups*512 threads):"]
+        by = collections.defaultdict(list)
+        for r in rows:
+            if dom in r["Kernel_Name"]:
+                by[(int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]))].append(dur(r))
+        smallest = min(by) if by else None
+        for k, v in sorted(by.items()):
+            lines.append(f"  grid {k}: calls {len(v):5d} avg {statistics.mean(v) / 1e3:7.2f} us  median {statistics.median(v) / 1e3:7.2f} us"
+                         f"  min {min(v) / 1e3:7.2f} us" + ("   <- the decode launch bench.py times" if k == smallest else ""))
     # one steady-state frame: from one predictor_input launch to the next
     idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("predictor_input_kernel")]
     if len(idx) > 3:
