@@ -381,6 +381,7 @@ def run_arrivals(fe, device, H, streams, frames, gap_s, lens, samplers, seed, ad
             "first_chunk_ms_p50": ms(percentile(list(first.values()), 0.5)), "first_chunk_ms_p99": ms(percentile(list(first.values()), 0.99)),
             "inter_chunk_ms_p50": ms(percentile(gaps, 0.5)), "inter_chunk_ms_p99": ms(percentile(gaps, 0.99)),
             "admission": ADMISSION_MODES[admission],
+            "first_chunk_ms": [ms(first[i]) for i in range(streams)],
             "note": "prefill and admission inside the timed region; first chunk = arrival -> the stream's first 16-code frame on the host"}
 
 
@@ -466,6 +467,16 @@ def main():
         run_arrivals(fe, device, H, 2, 3, 0.0, lens, (greedy_t, greedy_p), 1999, admission)      # (first use of the second stream)
         arrivals = run_arrivals(fe, device, H, B, ARRIVAL_FRAMES, ARRIVAL_GAP_S, lens, (greedy_t, greedy_p), 2000 + rank, admission)
         assert not fe.streams
+        # Eight arrivals are few: where an arrival falls inside the frame in flight decides its first chunk, and with a
+        # fixed gap the eight phases are one draw.  Two more runs with gaps that shift the phase (50.9 and 51.7 ms
+        # against a 2.5 ms frame) are pooled with the first for a steadier percentile.
+        pooled = list(arrivals["first_chunk_ms"])
+        for k, gap in enumerate((0.0509, 0.0517)):
+            more = run_arrivals(fe, device, H, B, ARRIVAL_FRAMES, gap, lens, (greedy_t, greedy_p), 2100 + 10 * k + rank, admission)
+            pooled += more["first_chunk_ms"]
+            assert not fe.streams
+        arrivals["first_chunk_ms_pooled"] = {"p50": percentile(pooled, 0.5), "p99": percentile(pooled, 0.99), "arrivals": len(pooled),
+                                             "gaps_ms": [ARRIVAL_GAP_S * 1e3, 50.9, 51.7]}
         # the same requests all at once (the reference's batch_async_example.py fires its streams together): admission packs
         # the prompts into one prefill
         together = run_arrivals(fe, device, H, B, ARRIVAL_FRAMES, 0.0, lens, (greedy_t, greedy_p), 3000 + rank, admission)
@@ -582,9 +593,12 @@ def main():
             "host": {"host_enqueue_ms_per_frame": host["step"]["host_enqueue_ms_per_frame"],
                      "serving_ms_per_frame": host["step"]["ms_per_frame"],
                      "polling": host["step_polling"],
+                     "launch_margin_ms": fe.launch_margin_s() * 1e3,
                      "note": "FrameEngine.step(): host time per frame not spent waiting (two graph launches, codes read-back, "
                              "bookkeeping); polling: the replica processes' form, the admission hook polled while the frame runs "
-                             "(host_cpu_ms_per_frame = process CPU time, sleeps between polls excluded)"},
+                             "(host_cpu_ms_per_frame = process CPU time, sleeps between polls excluded); launch_margin_ms: how long before "
+                             "the expected end of the talker step the polling form commits the next frame (follows the measured "
+                             "enqueue time)"},
         }
         if arrivals is not None:
             out["arrivals"] = arrivals

@@ -64,9 +64,14 @@ class FrameEngine:
     # newcomer has its first frame as early as it can).  False: with the first frame that starts after the prefill has
     # finished (the running streams never wait; the newcomer may lose most of a frame).
     join_prefills = True
-    # step(poll=): a frame is handed to the GPU this long before the talker step in front of it is expected to end
-    # (covers the host's wake-up granularity and the time it takes to enqueue the frame's graphs)
-    LAUNCH_MARGIN_S = 3.5e-4
+    # step(poll=): a frame is handed to the GPU this long before the talker step in front of it is expected to end.
+    # The margin covers the host's wake-up granularity and the time it takes to get the frame's first graph into the
+    # queue; the latter is measured per frame (`_commit_s`) and the margin follows it between the two bounds, so a
+    # host that shares its cores with other replicas commits earlier instead of leaving the GPU idle.  An instance
+    # that sets LAUNCH_MARGIN_S itself keeps that value.
+    LAUNCH_MARGIN_S = None
+    LAUNCH_MARGIN_MIN_S, LAUNCH_MARGIN_MAX_S = 2.5e-4, 1.0e-3
+    WAKE_UP_S = 1.0e-4                 # what a 50 us sleep can overshoot by, plus the poll hook's own time
 
     def __init__(self, model_dir: str, max_streams: int = 8, max_text_frames: int = 1024, talker_weights=None,
                  predictor_weights=None, enforce_eager: bool = False, codec_eos: int | None = CODEC_EOS, top_k: int = 50,
@@ -136,6 +141,7 @@ class FrameEngine:
         self._talker_pair = None
         self._talker_s = 0.0
         self._codes_s = 0.0                # running estimate: launch of a frame -> its codes on the host (step(poll=))
+        self._commit_s = 2.0e-4            # running estimate: end of the wait -> the frame's codes graph is in the queue
         # host time inside step() that was not spent waiting (enqueueing the frame's graphs, reading the codes, stream
         # bookkeeping), and the number of step() calls it was collected over: what a replica costs its host per frame
         self.host_busy_s, self.host_frames = 0.0, 0
@@ -564,13 +570,14 @@ class FrameEngine:
             # then.  A request that shows up in this window is prefilled right behind that talker step and is part of
             # this frame; had the frame been launched at once, the prefill would have queued behind the whole of it.
             begun, pair = self._talker_mark
-            deadline = begun + self._talker_s - self.LAUNCH_MARGIN_S
+            deadline = begun + self._talker_s - self.launch_margin_s()
             while time.perf_counter() < deadline and not pair[1].query():
                 poll()
                 t_w = time.perf_counter()
                 time.sleep(self._poll_sleep(deadline - t_w))
                 waited += time.perf_counter() - t_w
         self._talker_mark = None
+        t_commit = time.perf_counter()
         if not self.streams or not self._activate_or_wait():
             return {}
         bs = self._bucket()
@@ -582,6 +589,8 @@ class FrameEngine:
             # step that starts the next frame is already running (the reference yields before that step too,
             # P/interface.py:1241-1290)
             self._launch_codes(bs)
+            if poll is not None:
+                self._commit_s = 0.75 * self._commit_s + 0.25 * min(time.perf_counter() - t_commit, 2e-3)
             self._codes_host[:bs].copy_(self.codes[:bs], non_blocking=True)
             self._codes_event.record(torch.cuda.current_stream())
             if pair:
@@ -629,6 +638,12 @@ class FrameEngine:
         self.host_busy_s += time.perf_counter() - t_in - waited
         self.host_frames += 1
         return res
+
+    def launch_margin_s(self) -> float:
+        """How long before the expected end of the talker step in front of it a frame is committed to the GPU's queue."""
+        if self.LAUNCH_MARGIN_S is not None:
+            return self.LAUNCH_MARGIN_S
+        return min(self.LAUNCH_MARGIN_MAX_S, max(self.LAUNCH_MARGIN_MIN_S, self._commit_s + self.WAKE_UP_S))
 
     @staticmethod
     def _poll_sleep(remaining: float) -> float:
