@@ -409,6 +409,10 @@ def test_requests_admitted_while_a_frame_is_in_flight_give_the_same_ids(tmp_path
     # newcomers found during frame 1 have their first frame two calls later at the latest (frame 2 waits for them)
     assert len(got["s4"]) == 2 and all(0 <= c < 512 for fr in got["s4"] for c in fr)
     assert len(fe.talker.scheduler.block_manager.free_block_ids) == free0
+    # the polling form's commit margin follows the measured commit time between its bounds, unless an instance pins it
+    assert fe.LAUNCH_MARGIN_MIN_S <= fe.launch_margin_s() <= fe.LAUNCH_MARGIN_MAX_S
+    fe.LAUNCH_MARGIN_S = 4e-4
+    assert fe.launch_margin_s() == 4e-4
     fe.exit()
 
 

@@ -21,7 +21,7 @@ DEV = "cuda:0"
 SHAPES = {"talker": (2048, 6144, 3072), "predictor": (1024, 3072, 2048)}
 
 
-def _stack(kind, weight_dtype="bf16", seed=5, layers=2, max_rows=320):
+def _stack(kind, weight_dtype="bf16", seed=5, layers=2, max_rows=320, kv_blocks=48):
     from nano_qwen3tts_vllm import hip
     from nano_qwen3tts_vllm.models.hip_decoder import DecoderShape, HipDecoder
     H, I, V = SHAPES[kind]
@@ -30,7 +30,7 @@ def _stack(kind, weight_dtype="bf16", seed=5, layers=2, max_rows=320):
     w = _weights(shape, seed)
     g = torch.Generator().manual_seed(seed + 1)
     w["head.weight"] = (torch.randn(V, H, generator=g) * 0.05).bfloat16()
-    dec = HipDecoder(w, shape, num_kv_blocks=48, max_rows=max_rows, device=DEV, weight_dtype=weight_dtype)
+    dec = HipDecoder(w, shape, num_kv_blocks=kv_blocks, max_rows=max_rows, device=DEV, weight_dtype=weight_dtype)
     head = hip.pack_weight(w["head.weight"].to(DEV))
     cfg = O.DecoderCfg(H, layers, 16, 8, 128, I, V, 1e-6, 1000000.0)
     return dec, head, w, cfg
@@ -53,9 +53,11 @@ def _close(got, want, alt, what):
 
 @pytest.mark.parametrize("kind,lens", [("talker", (20,)), ("talker", (33,)), ("talker", (64,)), ("talker", (100,)), ("talker", (200,)),
                                        ("talker", (17, 30)), ("predictor", (20,)), ("predictor", (40,)), ("predictor", (64,)),
-                                       ("predictor", (130,)), ("predictor", (2,) * 12), ("predictor", (2,) * 40)])
+                                       ("predictor", (130,)), ("predictor", (2,) * 12), ("predictor", (2,) * 40),
+                                       # either side of the row counts up to which the norms ride in the GEMMs
+                                       ("talker", (65,)), ("talker", (48, 16)), ("predictor", (256,)), ("predictor", (257,))])
 def test_prompt_rows_against_the_oracle_stack(kind, lens):
-    """Packed prompts of 17..200 rows (the predictor's 2-position prompts of 12 and 40 streams included) through two
+    """Packed prompts of 17..257 rows (the predictor's 2-position prompts of 12 and 40 streams included) through two
     layers + final norm + head: hidden state and logits against the oracle."""
     dec, head, w, cfg = _stack(kind)
     H, V = cfg.hidden_size, cfg.vocab_size
@@ -64,10 +66,14 @@ def test_prompt_rows_against_the_oracle_stack(kind, lens):
     x = (torch.randn(N, H, generator=g) * 0.5).bfloat16()
     pos = torch.cat([torch.arange(L) for L in lens]).to(torch.int64)
     rs = torch.cat([torch.full((L,), i) for i, L in enumerate(lens)]).to(torch.int32)
-    slots = (rs.to(torch.int64) * 256 + pos).to(torch.int32)
+    # sequence i owns the KV blocks from first[i] on (a prompt of more than 256 tokens has two)
+    nblk = [(L + 255) // 256 for L in lens]
+    first = [sum(nblk[:i]) for i in range(len(lens))]
+    slots = (torch.tensor(first)[rs.long()] * 256 + pos).to(torch.int32)
     ctx = (pos + 1).to(torch.int32)
     bt = torch.zeros(len(lens), 4, dtype=torch.int32)
-    bt[:, 0] = torch.arange(len(lens))
+    for i in range(len(lens)):
+        bt[i, :nblk[i]] = torch.arange(first[i], first[i] + nblk[i])
     hidden = torch.zeros(N, H, dtype=torch.bfloat16, device=DEV)
     logits = torch.zeros(N, V, dtype=torch.bfloat16, device=DEV)
     dec.forward_logits(x.to(DEV), pos.to(DEV), slots.to(DEV), ctx.to(DEV), bt.to(DEV), max(lens), head, V, hidden, logits,
@@ -88,13 +94,13 @@ def test_prompt_rows_against_the_oracle_stack(kind, lens):
 
 
 @pytest.mark.parametrize("kind,B,L", [("talker", 20, 6), ("talker", 40, 3), ("predictor", 24, 5), ("predictor", 48, 2),
-                                      ("predictor", 17, 9)])
+                                      ("predictor", 17, 9), ("talker", 64, 2), ("talker", 72, 2), ("predictor", 128, 2)])
 def test_decode_steps_of_more_than_sixteen_rows_against_the_oracle_stack(kind, B, L):
     """B sequences prefilled with L tokens each (one packed step), then ONE decode step of B rows: every row against the
     oracle's stack over the sequence's L + 1 tokens (causal attention: the last row of that prompt is the decode step).
     This is the step a frame of 17+ streams runs - decode attention writing its rows in fragment order for o_proj, the
     norms inside the GEMMs."""
-    dec, head, w, cfg = _stack(kind, seed=9)
+    dec, head, w, cfg = _stack(kind, seed=9, kv_blocks=max(48, B))
     H, V = cfg.hidden_size, cfg.vocab_size
     g = torch.Generator().manual_seed(B * 100 + L)
     xs = [(torch.randn(L + 1, H, generator=g) * 0.5).bfloat16() for _ in range(B)]
