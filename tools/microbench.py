@@ -344,7 +344,7 @@ def frame():
 
 
 def decode_eager():
-    """The talker's decode step (28 layers) and the predictor's burst at 8 streams, launched eagerly a few times (no
+    """The talker's decode step (28 layers) and the predictor's burst at QTTS_STREAMS (8) streams, launched eagerly a few times (no
     graph: counter collection under the profiler is per launch), contexts of QTTS_FRAME_PROMPT + a few tokens."""
     import json, tempfile
     sys.path.insert(0, ROOT)
@@ -356,7 +356,7 @@ def decode_eager():
     tw, pw = bench.make_weights(cfg, dev)
     d = tempfile.mkdtemp()
     json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
-    B = 8
+    B = int(os.environ.get("QTTS_STREAMS", "8"))
     fe = FrameEngine(d, max_streams=B, max_text_frames=64, talker_weights=tw, predictor_weights=pw,
                      num_kvcache_blocks=4 * B, max_num_batched_tokens=4096, codec_eos=None, enforce_eager=True)
     sp = SamplingParams(temperature=1.0, max_tokens=1, do_sample=False)
