@@ -126,11 +126,12 @@ def main():
                         os.path.join(P, f"{RND}_bench_summary_32streams.txt"),
                         "rocprofv3 --kernel-trace --stats -- python3 bench.py --streams 32 --steps 30 --warmup 5 --no-cpu-baseline --no-arrivals   (MI355X)"],
                        check=True, stdout=subprocess.DEVNULL)
-    if os.path.exists(os.path.join(R, "soak.json")):
-        try:
-            json.dump(last_json(os.path.join(R, "soak.json")), open(os.path.join(P, f"{RND}_soak.json"), "w"), indent=1)
-        except Exception as e:
-            print("soak output not collected:", e)
+    for name in ("soak", "soak_32rows"):
+        if os.path.exists(os.path.join(R, name + ".json")):
+            try:
+                json.dump(last_json(os.path.join(R, name + ".json")), open(os.path.join(P, f"{RND}_{name}.json"), "w"), indent=1)
+            except Exception as e:
+                print(name, "output not collected:", e)
     pb = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prefill_breakdown.py"), os.path.join(R, "prefill_trace")],
                         capture_output=True, text=True, check=True).stdout
     with open(os.path.join(P, f"{RND}_prefill.txt"), "w") as fo:

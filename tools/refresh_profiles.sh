@@ -59,6 +59,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tra
 cd $R
 step soak
 QTTS_SOAK_STEPS=1500 QTTS_SOAK_REPLAY_STEPS=500 timeout -k 10 500 python3 -u tools/soak.py > $O/soak.json 2>> $O/err.log
+QTTS_SOAK_STREAMS=32 QTTS_SOAK_STEPS=1500 QTTS_SOAK_REPLAY_STEPS=500 timeout -k 10 500 python3 -u tools/soak.py > $O/soak_32rows.json 2>> $O/err.log
 step rows
 QTTS_ROWS=32,64,128,200,400 timeout -k 10 300 python3 -u tools/microbench.py rows > $O/rows.txt 2>> $O/err.log
 step collect

@@ -35,7 +35,7 @@ from nano_qwen3tts_vllm.utils import synthetic  # noqa: E402
 
 def run_schedule(seed, steps, d, H, tv, pv, tw, pw, dev, timing_free):
     rnd = random.Random(seed)
-    B = 8
+    B = int(os.environ.get("QTTS_SOAK_STREAMS", "8"))      # stream rows of the engine (more than 16: the steps run the prompt-form GEMMs)
     fe = FrameEngine(d, max_streams=B, max_text_frames=320, talker_weights=tw, predictor_weights=pw, num_kvcache_blocks=4 * B,
                      max_num_batched_tokens=4096, codec_eos=None)
     fe.capture_all()
@@ -82,7 +82,7 @@ def run_schedule(seed, steps, d, H, tv, pv, tw, pw, dev, timing_free):
     step = 0
     while step < steps or fe.streams:
         step += 1
-        if step < steps and len(fe.streams) < B and rnd.random() < 0.5:
+        if step < steps and len(fe.streams) < B and rnd.random() < (0.5 if B <= 8 else 0.85):
             room = B - len(fe.streams)
             how = rnd.random()
             if how < 0.4 and room >= 2:                       # several at once: one packed prefill
@@ -151,7 +151,7 @@ def main():
     assert sorted(a) == sorted(b), "the two replay runs served different streams"
     differ = [sid for sid in a if a[sid] != b[sid]]
     assert not differ, f"{len(differ)} of {len(a)} streams differ between two runs of the same schedule: {differ[:5]}"
-    print(json.dumps(dict(seconds=round(time.time() - t0, 1), streams=len(finished), replayed_streams_identical=len(a),
+    print(json.dumps(dict(seconds=round(time.time() - t0, 1), stream_rows=int(os.environ.get("QTTS_SOAK_STREAMS", "8")), streams=len(finished), replayed_streams_identical=len(a),
                           replayed_sampled=ca["sampled"], **counts)))
 
 
