@@ -114,7 +114,7 @@ def main():
     json.dump(out, open(os.path.join(P, f"{RND}_pmc_mfma.json"), "w"), indent=1)
 
     sweep = []
-    for S in (1, 8, 16, 24, 32, 64, 128):
+    for S in (1, 8, 16, 24, 32, 64, 128, 256):
         x = bench if S == 8 else last_json(os.path.join(R, f"sweep_{S}.json"))
         sweep.append({"streams_per_gpu": S, "codec_tokens_per_s": round(x["value"]), "ms_per_frame": round(x["ms_per_step"], 3),
                       "rtf": round(x["rtf"], 4), "frame_roofline_frac": round(x["frame_roofline"]["frac"], 3), "steps": x["steps"]})

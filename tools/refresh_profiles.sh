@@ -50,7 +50,7 @@ timeout -k 10 300 python3 -u examples/batch_async_example.py --streams 8 --engin
 timeout -k 10 300 python3 -u examples/quick_benchmark.py --sample > $O/api_quick_benchmark_sampling.json 2> $O/qbs.err
 timeout -k 10 300 python3 -u examples/batch_async_example.py --streams 8 --sample > $O/api_batch_async_fused_sampling.json 2> $O/bas.err
 step sweep
-for S in 1 16 24 32 64 128; do
+for S in 1 16 24 32 64 128 256; do
   timeout -k 10 300 python3 -u bench.py --streams $S --steps 50 --warmup 5 --no-cpu-baseline --no-arrivals > $O/sweep_$S.json 2>> $O/err.log
 done
 step trace-32-streams
