@@ -520,7 +520,18 @@ struct AttnFusedArgs {
     int *counters;
     const int64_t *row_ids; int id_rows;   // non-null: row r of the launch reads qkv row row_ids[r] (a table of rows)
     int opks;                              // > 0: `out` in fragment order (act_index) with this many k-steps
+#ifdef QTTS_TUNING
+    long long *trace;                      // 8 timestamps per workgroup (the traced launch), or null
+#endif
 };
+
+#ifdef QTTS_TUNING
+// slot s of this workgroup's timestamps; `dep` is a value the stamp must not be taken before
+#define QTTS_ATRACE(slot, dep) do { asm volatile("" ::"v"(dep) : "memory"); if (p.trace && threadIdx.x == 0) \
+    p.trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define QTTS_ATRACE(slot, dep) do { } while (0)
+#endif
 
 // wv: the lane's 8 norm weights; cv, sv: its 8 cos / sin values (dims d and d + 64 share them)
 __device__ __forceinline__ void norm_rope8(const float (&x)[8], const Frag &wv, const Frag &cv, const Frag &sv, float eps,
@@ -584,6 +595,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
     static_assert(NG >= G + 1, "one sixteen-lane group per head row to normalise");
     const int row = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
     const int t0 = split * SPLIT;
+    QTTS_ATRACE(0, t0);
     // A workgroup's tokens lie in one 256-token KV block (SPLIT divides 256): its table entry does not depend on the
     // context length, so both are requested together instead of one round trip after the other.
     static_assert(QTTS_KV_BLOCK % SPLIT == 0, "a workgroup's token range must not straddle KV blocks");
@@ -601,6 +613,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
     asm volatile("" ::"s"(blk_all), "s"(ctx), "s"(slot_raw), "s"(pos), "s"(p.kc), "s"(p.vc), "s"(p.cosT), "s"(p.sinT),
                  "s"(p.qw), "s"(p.kw), "s"(p.out), "s"(qrow));
     if (IDS) qrow = qrow < 0 ? 0 : (qrow >= p.id_rows ? p.id_rows - 1 : qrow);
+    QTTS_ATRACE(1, ctx);
     const int slot = (UNIFORM || a_slots) ? slot_raw : -1;
     const int Hq = a_Hq, Hkv = a_Hkv;
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -632,17 +645,31 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
     // with the "no token" value), i.e. one round trip per token instead of all requests in flight together.  A
     // lane without a cached token (the new token, or past the context) reads this row's raw k/v instead: finite
     // values whose weight is zero, and for the new token V as it is wanted.
+    __builtin_amdgcn_sched_barrier(0);      // (the requests above are not to be scheduled behind the ones below)
+    // Order of the requests (a wave's requests return in the order they were made): the row, the norm weights and the
+    // cos / sin row first - the q / k normalisation below needs only those and is done while the cached rows are
+    // still on their way -, then every K row, then every V row: the scores are complete when the K half has
+    // arrived, the weighted sum follows the V rows in.
     Frag kk[TPG], vv[TPG];
     const bf16_t *krow = rowp + (size_t)(Hq + kvh) * 128 + 8 * l16;
     const bf16_t *vrow = rowp + (size_t)(Hq + Hkv + kvh) * 128 + 8 * l16;
 #pragma unroll
     for (int i = 0; i < TPG; ++i) {
         const int t = t0 + i * NG + grp;
-        const bool cached = t < ctx - 1;
         const size_t off = (((size_t)blk_all * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
-        kk[i].u = *reinterpret_cast<const uint4 *>(cached ? p.kc + off : krow);
-        vv[i].u = *reinterpret_cast<const uint4 *>(cached ? p.vc + off : vrow);
+        kk[i].u = *reinterpret_cast<const uint4 *>(t < ctx - 1 ? p.kc + off : krow);
     }
+#pragma unroll
+    for (int i = 0; i < TPG; ++i) {
+        const int t = t0 + i * NG + grp;
+        const size_t off = (((size_t)blk_all * QTTS_KV_BLOCK + (t & 255)) * Hkv + kvh) * 128 + 8 * l16;
+        vv[i].u = *reinterpret_cast<const uint4 *>(t < ctx - 1 ? p.vc + off : vrow);
+    }
+    // (a use outside the branch below: without it the compiler moves the cos / sin and weight requests into that
+    // branch, behind the K / V requests, and the normalisation waits for every cached row)
+    asm volatile("" ::"v"(xr.u.x), "v"(xr.u.y), "v"(xr.u.z), "v"(xr.u.w), "v"(wv.u.x), "v"(wv.u.y), "v"(wv.u.z), "v"(wv.u.w),
+                 "v"(cv.u.x), "v"(cv.u.y), "v"(cv.u.z), "v"(cv.u.w), "v"(sv.u.x), "v"(sv.u.y), "v"(sv.u.z), "v"(sv.u.w),
+                 "v"(vnew.u.x), "v"(vnew.u.y), "v"(vnew.u.z), "v"(vnew.u.w));
 
     Frag knew;
     if (grp <= G) {
@@ -663,6 +690,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
         }
     }
     __syncthreads();
+    QTTS_ATRACE(2, ctx);
     float qf[G][8];
 #pragma unroll
     for (int h = 0; h < G; ++h) {
@@ -697,6 +725,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
             sc[i][h] = t < ctx ? s : -INFINITY;
         }
     }
+    QTTS_ATRACE(3, sc[0][0]);
     float mx[G], ls[G], acc[G][8];
 #pragma unroll
     for (int h = 0; h < G; ++h) {
@@ -732,6 +761,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
         }
     }
     __syncthreads();
+    QTTS_ATRACE(4, ctx);
     const bool direct = nact == 1;
     for (int e = threadIdx.x; e < G * 128; e += NT) {
         const int h = e >> 7, d = e & 127;
@@ -772,6 +802,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
             }
         }
     }
+    QTTS_ATRACE(5, ctx);
     if (direct) return;
     // The last of the row's workgroups to arrive merges the partials.  Partials and counter are accessed
     // with device-scope atomics only (they go to the level all XCDs share), the barrier waits for this
@@ -791,6 +822,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
         sm_last = old == nact - 1;
     }
     __syncthreads();
+    QTTS_ATRACE(6, ctx);
     if (!sm_last) return;
     for (int e = threadIdx.x; e < G * 128; e += NT) {
         const int h = e >> 7, d = e & 127;
@@ -829,6 +861,7 @@ __global__ __launch_bounds__(NG * 16) void attn_decode_fused_kernel(const int32_
         p.out[act_index(row, hq * 128 + d, p.ldo, p.opks)] = f2bf(o / L);
     }
     if (threadIdx.x == 0) __hip_atomic_store(p.counters + row * Hkv + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    QTTS_ATRACE(7, ctx);
 }
 
 static inline int attn2_nsplit(int max_context) { return (max_context + ATT2_SPLIT - 1) / ATT2_SPLIT; }
@@ -872,6 +905,9 @@ int attention_decode_fused_impl(const void *qkv, int ldqkv, const void *q_norm_w
     a.part_o = (float *)partials; a.part_ml = a.part_o ? a.part_o + (size_t)B * Hq * ns * 128 : nullptr; a.nsplit = ns;
     a.counters = counters;
     a.row_ids = row_ids; a.id_rows = id_rows;
+#ifdef QTTS_TUNING
+    a.trace = g_trace;                      // (armed by qtts_debug_linear_trace: 8 words per workgroup of this launch)
+#endif
     QCHECK(opks == 0 || opks * 32 == Hq * 128, "attention_decode_fused: fragment-order output rows have Hq*128 columns (whole 16-row tiles)");
     a.opks = opks;
     dim3 grid(B, Hkv, ns);

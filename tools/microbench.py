@@ -444,7 +444,10 @@ def attn():
     """The talker's fused decode attention launch (q/k norm + RoPE + store + paged attention) at QTTS_ATTN_ROWS rows and
     QTTS_ATTN_CTX tokens of context, cycling through 28 layers' caches inside one graph (cold K/V)."""
     from nano_qwen3tts_vllm.models.hip_decoder import rope_tables
-    Hq, Hkv, nl = 16, 8, 28
+    # QTTS_ATTN_HEADS="2,1" with eight times the rows: the same bytes and workgroups with every (row, KV head)'s cached
+    # rows contiguous (what a head-major KV block would look like to the kernel)
+    Hq, Hkv = [int(v) for v in os.environ.get("QTTS_ATTN_HEADS", "16,8").split(",")]
+    nl = 28
     for B in [int(v) for v in os.environ.get("QTTS_ATTN_ROWS", "8,32,64").split(",")]:
         for ctx in [int(v) for v in os.environ.get("QTTS_ATTN_CTX", "150,290,400,500").split(",")]:
             nb = (ctx + 255) // 256
@@ -483,6 +486,56 @@ def attn():
                 line += f"  {('per shape', '128-token workgroups', '256-token workgroups')[wide]} {us:6.2f} us"
             hip.lib.qtts_tune_attn_wide(0)
             print(line, flush=True)
+            del kc, vc
+
+
+def attntrace():
+    """Timestamps inside one fused decode-attention launch at the talker's shape (QTTS_ATTN_ROWS rows, QTTS_ATTN_CTX tokens):
+    per workgroup, when it started, had its metadata, had q / k normalised, had its scores (K rows in), had left its
+    partial sums in LDS (V rows in), had stored its partials, knew whether it was the row's last, and ended."""
+    import numpy as np
+    from nano_qwen3tts_vllm.models.hip_decoder import rope_tables
+    Hq, Hkv, nl = 16, 8, 4
+    names = ["start", "metadata in", "q/k normalised", "scores (K in)", "LDS partials (V in)", "partials stored", "arrival known", "end (merging workgroups)"]
+    for B in [int(v) for v in os.environ.get("QTTS_ATTN_ROWS", "8,32,64").split(",")]:
+        for ctx in [int(v) for v in os.environ.get("QTTS_ATTN_CTX", "200,300").split(",")]:
+            nb = (ctx + 255) // 256
+            kc = torch.randn(nl, B * nb, 256, Hkv, 128, device=dev, dtype=torch.bfloat16)
+            vc = torch.randn(nl, B * nb, 256, Hkv, 128, device=dev, dtype=torch.bfloat16)
+            qkv = torch.randn(B, (Hq + 2 * Hkv) * 128, device=dev).bfloat16()
+            qw = torch.ones(128, device=dev).bfloat16()
+            ct, st = rope_tables(128, 1000000.0, 2048)
+            ct, st = ct.to(dev), st.to(dev)
+            bt = torch.zeros(B, 4, dtype=torch.int32)
+            for i in range(B):
+                bt[i, :nb] = torch.arange(i * nb, (i + 1) * nb)
+            bt = bt.to(dev)
+            lens = torch.tensor([max(1, ctx - (7 * i) % 40) for i in range(B)], dtype=torch.int32)
+            cl, pos = lens.to(dev), lens.to(torch.int64).to(dev)
+            slots = torch.tensor([int(bt[i, (int(c) - 1) // 256]) * 256 + (int(c) - 1) % 256 for i, c in enumerate(lens)], dtype=torch.int32).to(dev)
+            out = torch.empty(B, Hq * 128, dtype=torch.bfloat16, device=dev)
+            ws = torch.zeros(hip.lib.qtts_attn_decode_workspace_bytes(B, Hq, Hkv, ctx), dtype=torch.uint8, device=dev)
+            buf = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+
+            def call(l):
+                hip.check(hip.lib.qtts_attention_decode_fused(hip.ptr(qkv), qkv.stride(0), hip.ptr(qw), hip.ptr(qw), 1e-6, hip.ptr(ct), hip.ptr(st),
+                                                              2048, hip.ptr(pos), hip.ptr(slots), hip.ptr(kc[l]), hip.ptr(vc[l]), hip.ptr(bt), 4,
+                                                              hip.ptr(cl), ctx, 128 ** -0.5, hip.ptr(out), Hq * 128, B, Hq, Hkv, hip.ptr(ws), hip.stream()))
+            for l in range(nl - 1):
+                call(l)
+            torch.cuda.synchronize()
+            hip.lib.qtts_debug_linear_trace(hip.ptr(buf))
+            call(nl - 1)
+            hip.lib.qtts_debug_linear_trace(None)
+            torch.cuda.synchronize()
+            t = buf.cpu().numpy().reshape(4096, 8).astype(np.float64) * 10.0
+            t = t[t[:, 0] > 0]
+            t0 = t[:, 0].min()
+            print(f"attention B={B} ctx={ctx}: {len(t)} workgroups, ns after the first workgroup's start (median / max over the workgroups that got there)")
+            for k, name in enumerate(names):
+                v = t[:, k][t[:, k] > 0] - t0
+                if len(v):
+                    print(f"  {name:26s} median {np.median(v):7.0f}  max {v.max():7.0f}  (n={len(v)})")
             del kc, vc
 
 
@@ -620,4 +673,4 @@ def prefill():
 
 if __name__ == "__main__":
     _tuning.apply_env_flags()
-    {"prefill": prefill, "prefill_batch": prefill_batch, "decode_eager": decode_eager, "rows": rows, "rowsn": rowsn, "attn": attn, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "mall": mall, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
+    {"prefill": prefill, "prefill_batch": prefill_batch, "decode_eager": decode_eager, "rows": rows, "rowsn": rowsn, "attn": attn, "attntrace": attntrace, "rowtrace": rowtrace, "launch": launch, "linear": linear, "linear2": linear2, "frame": frame, "dominant": dominant, "lat": lat, "mall": mall, "gridbar": gridbar, "trace": trace}[sys.argv[1]]()
