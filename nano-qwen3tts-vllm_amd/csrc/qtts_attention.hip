@@ -987,6 +987,9 @@ __global__ __launch_bounds__(64) void attn_pair_kernel(const bf16_t *__restrict_
     fq.u = *reinterpret_cast<const uint4 *>(qkv + (size_t)(2 * seq + 1) * ld + (size_t)(kvh * G + grp) * 128 + 8 * l16);
     qwv.u = *reinterpret_cast<const uint4 *>(qw + 8 * l16);
     kwv.u = *reinterpret_cast<const uint4 *>(kw + 8 * l16);
+    // (positions and slots of both rows are wanted here, with the first batch: left alone, the compiler requests each
+    // where it is first used and waits for it there, one round trip after the other)
+    asm volatile("" ::"v"((int)pos[0]), "v"((int)(pos[0] >> 32)), "v"((int)pos[1]), "v"((int)(pos[1] >> 32)), "v"(slot[0]), "v"(slot[1]));
     Frag cv[2], sv[2];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -994,6 +997,16 @@ __global__ __launch_bounds__(64) void attn_pair_kernel(const bf16_t *__restrict_
         cv[rr].u = *reinterpret_cast<const uint4 *>(cosT + p * 64 + ((8 * l16) & 63));
         sv[rr].u = *reinterpret_cast<const uint4 *>(sinT + p * 64 + ((8 * l16) & 63));
     }
+#define QPIN4(f) "v"((f).u.x), "v"((f).u.y), "v"((f).u.z), "v"((f).u.w)
+    // (whole 16-byte requests, all of them up here: the compiler otherwise narrows a request to the words used first
+    // and fetches the rest where it is used, behind a wait for everything)
+    asm volatile("" ::QPIN4(kraw[0]), QPIN4(kraw[1]), QPIN4(vb[0]), QPIN4(vb[1]), QPIN4(fq), QPIN4(qwv), QPIN4(kwv));
+    // (all four cos / sin requests in one batch: left alone, the compiler asks for the second row's where they are
+    // first used, one round trip later)
+    asm volatile("" ::"v"(cv[0].u.x), "v"(cv[0].u.y), "v"(cv[0].u.z), "v"(cv[0].u.w), "v"(sv[0].u.x), "v"(sv[0].u.y), "v"(sv[0].u.z),
+                 "v"(sv[0].u.w), "v"(cv[1].u.x), "v"(cv[1].u.y), "v"(cv[1].u.z), "v"(cv[1].u.w), "v"(sv[1].u.x), "v"(sv[1].u.y),
+                 "v"(sv[1].u.z), "v"(sv[1].u.w));
+#undef QPIN4
     Frag kb[2];
     float x[8], o8[8];
 #pragma unroll
