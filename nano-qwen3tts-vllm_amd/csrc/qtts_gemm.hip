@@ -911,6 +911,43 @@ __global__ __launch_bounds__(256) void linear_parts_norm_kernel(const float *par
     // rpks / opks0 > 0: the residual rows / `out` in fragment order (act_index; a thread's 8 columns stay contiguous)
     __shared__ float red[4];
     const int m = blockIdx.x;
+    if (N <= 256 * 8) {
+        // One pass (as in rmsnorm_kernel): the finished row stays in registers across the reduction and the norm
+        // weights are requested with everything else; same arithmetic, same order of additions.
+        const int n = threadIdx.x * 8;
+        const bool on = n < N;
+        const int nc = on ? n : 0;
+        float q[8];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const float4_t sum = sum_k_parts(part, (size_t)m * N + nc + 4 * hlf, (size_t)mpad * N, kparts);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[4 * hlf + j] = sum[j];
+        }
+        Frag rf, bfv, o;
+        rf.u = res ? *reinterpret_cast<const uint4 *>(res + act_index(m, nc, ldr, rpks)) : make_uint4(0, 0, 0, 0);
+        bfv.u = bias ? *reinterpret_cast<const uint4 *>(bias + nc) : make_uint4(0, 0, 0, 0);
+        const uint4 wv = *reinterpret_cast<const uint4 *>(nw + nc);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = q[j];
+            if (bias) v += bf2f(bfv.h[j]);
+            v = rbf(v);
+            if (res) v = v + bf2f(rf.h[j]);
+            o.h[j] = f2bf(v);
+            const float r = bf2f(o.h[j]);
+            if (on) ss += r * r;
+        }
+        if (on) *reinterpret_cast<uint4 *>(out + act_index(m, n, ldo, opks0)) = o.u;
+        for (int of = 32; of > 0; of >>= 1) ss += __shfl_xor(ss, of);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        const float rstd = 1.0f / sqrtf(tot / (float)N + eps);
+        if (on) *reinterpret_cast<uint4 *>(xn + act_index(m, n, ldxn, xnpks)) = norm_frag(o.u, rstd, wv);
+        return;
+    }
     float ss = 0.f;
     for (int n = threadIdx.x * 8; n < N; n += 256 * 8) {
         float q[8];
@@ -1336,6 +1373,31 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t *__restrict__
                                                       float eps, bf16_t *__restrict__ y, int ldy, int H, int ypks, int xpks) {
     __shared__ float red[4];
     const int row = blockIdx.x;
+    if (H <= 256 * 8) {
+        // One pass: a thread's 8 columns and their weights are requested together and stay in registers across the
+        // reduction (the general form below reads the row a second time and asks for the weights only then, one
+        // round trip later).  Same additions in the same order.
+        const int i = threadIdx.x * 8;
+        const bool on = i < H;
+        Frag f;
+        f.u = *reinterpret_cast<const uint4 *>(x + act_index(row, on ? i : 0, ldx, xpks));
+        const uint4 wv = *reinterpret_cast<const uint4 *>(w + (on ? i : 0));
+        float ss = 0.f;
+        if (on) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = bf2f(f.h[j]);
+                ss += v * v;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        const float tot = red[0] + red[1] + red[2] + red[3];
+        const float rstd = 1.0f / sqrtf(tot / (float)H + eps);
+        if (on) *reinterpret_cast<uint4 *>(y + act_index(row, i, ldy, ypks)) = norm_frag(f.u, rstd, wv);
+        return;
+    }
     float ss = 0.f;
     for (int i = threadIdx.x * 8; i < H; i += 256 * 8) {
         Frag f;
