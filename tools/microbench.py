@@ -517,7 +517,14 @@ def attntrace():
             ws = torch.zeros(hip.lib.qtts_attn_decode_workspace_bytes(B, Hq, Hkv, ctx), dtype=torch.uint8, device=dev)
             buf = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
 
+            uniform = os.environ.get("QTTS_ATTN_UNIFORM") == "1" and ctx <= 32      # rows without metadata (a burst step)
+
             def call(l):
+                if uniform:
+                    hip.check(hip.lib.qtts_attention_decode_fused(hip.ptr(qkv), qkv.stride(0), hip.ptr(qw), hip.ptr(qw), 1e-6, hip.ptr(ct), hip.ptr(st),
+                                                                  2048, None, None, hip.ptr(kc[l]), hip.ptr(vc[l]), None, 1,
+                                                                  None, ctx, 128 ** -0.5, hip.ptr(out), Hq * 128, B, Hq, Hkv, hip.ptr(ws), hip.stream()))
+                    return
                 hip.check(hip.lib.qtts_attention_decode_fused(hip.ptr(qkv), qkv.stride(0), hip.ptr(qw), hip.ptr(qw), 1e-6, hip.ptr(ct), hip.ptr(st),
                                                               2048, hip.ptr(pos), hip.ptr(slots), hip.ptr(kc[l]), hip.ptr(vc[l]), hip.ptr(bt), 4,
                                                               hip.ptr(cl), ctx, 128 ** -0.5, hip.ptr(out), Hq * 128, B, Hq, Hkv, hip.ptr(ws), hip.stream()))
