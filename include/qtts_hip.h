@@ -310,9 +310,11 @@ int qtts_model_forward_logits(qtts_model_t *m, const void *x, const int64_t *pos
                               const int32_t *context_lens, const int32_t *block_tables, int max_blocks,
                               int max_context, int N, void *hidden_out, const void *head_w_packed,
                               int vocab, void *logits_out, qtts_stream_t stream);
-/* A decode step (N <= 16 rows, one per sequence) whose input rows are rows of a table: row r = x_table[ids[r]],
- * x_table [table_rows, hidden] bf16, read in place by layer 0 (qkv GEMM input, o_proj residual); ids are device
- * data and clamped to the table.  qkv0_table (may be NULL) [table_rows, (Hq+2Hkv)*128] holds, per table row,
+/* A decode step (one row per sequence) whose input rows are rows of a table: row r = x_table[ids[r]],
+ * x_table [table_rows, hidden] bf16; ids are device data and clamped to the table.  Up to 16 rows the table rows are
+ * read in place by layer 0 (qkv GEMM input, o_proj residual); a step of more than 16 rows needs qkv0_table and
+ * copies its x rows into the model's workspace first (one gather launch).
+ * qkv0_table (may be NULL up to 16 rows) [table_rows, (Hq+2Hkv)*128] holds, per table row,
  * layer 0's input norm + qkv projection of that row; with it layer 0's qkv GEMM is not launched and its
  * attention reads the table rows (needs max_context <= 32 unless Hq/Hkv == 4).  Both tables are functions of the
  * weights only: for the code predictor x_table[i] = small_to_mtp_projection(codec_embedding[i].weight) and
